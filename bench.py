@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training samples/s of the fusion hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+N>1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(one rank per GPU, RCCL).  A step = zero_grad -> forward -> sigmoid focal loss (soft target) ->
+backward (-> bucketed gradient all-reduce overlapped with backward) -> AdamW step, train mode with
+the reference's dropout 0.1 and batch-statistics BatchNorm, on one synthetic batch that is already
+resident in HBM.  Workload = BASELINE.json configs[2] (full camera+LiDAR+radar+GPS fusion, 5-step
+sequence, bs=12 per GPU); configs[1] ("image-only") is the same compute with zeroed LiDAR/radar
+ and configs[0] is the CPU plumbing case timed here as `cpu_baseline`.
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline     : dominant kernel = the implicit-GEMM instantiation with the largest share of step time;
+                 achieved = algorithmic FLOPs of its launches / their HIP-event time, measured live in one
+                 extra instrumented step on the launch stream; peak = 157.3 TFLOP/s (fp32 MFMA, gfx950)
+  cpu_baseline : the CPU oracle (oracle/, torch fp32 on the host cores) timed on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+VARIANT_NAMES = {0: "128x128", 1: "128x64", 2: "64x64"}
+MODE_NAMES = {0: "fwd", 1: "dgrad", 2: "wgrad"}
+
+
+def host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = n
+    try:  # cgroup v2 cpu quota (the GPU box gives each job a share of a 256-thread host)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    return max(1, min(n, quota))
+
+
+def cpu_baseline(batch, steps):
+    """fwd + focal + bwd + AdamW of the CPU oracle on the host cores (reference CPU path restated)."""
+    from oracle import fusion_ref as fr
+    from oracle import train_ref as tr
+    cores = host_threads()
+    torch.set_num_threads(cores)
+    cfg = fr.RefConfig()
+    sd = fr.make_state(cfg, seed=0, scheme="init")
+    params = [v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not fr.is_buffer(k)]
+    opt = torch.optim.AdamW(params, lr=1e-4)
+    imgs, lids, rads, gps, target, _ = fr.make_inputs(cfg, batch, seed=100)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        logits = fr.transfuser_forward(sd, imgs, lids, rads, gps, cfg, fr.Ctx(training=True, dropout=True))
+        loss = tr.sigmoid_focal_loss(logits, target)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    timed = times[1:]
+    return dict(value=batch * len(timed) / sum(timed), unit="samples/s", cores=cores, kind="port",
+                sample=f"{len(timed)} timed steps (+1 warm-up) of bs={batch}, fp32, torch {torch.__version__} CPU, "
+                       f"oracle/fusion_ref.py fwd+focal+bwd+AdamW")
+
+
+class IgemmTimer:
+    """Brackets every implicit-GEMM launch of one step with HIP events on the launch stream."""
+
+    def __init__(self):
+        self.records = []  # (variant, flops, ev0, ev1)
+
+    def install(self):
+        from deepsense6g_tii_amd import ops
+        from deepsense6g_tii_amd._lib import lib
+        L = lib()
+        self._orig = {}
+        timer = self
+
+        def wrap(name, flops_fn):
+            orig = getattr(L, name)
+            self._orig[name] = orig
+
+            def call(*a):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                orig(*a)
+                e1.record()
+                timer.records.append((L.last_igemm_variant(), flops_fn(a), e0, e1))
+            setattr(L, name, call)
+
+        def conv_flops(a):  # (x, w, y, N, H, W, C, K, R, S, stride, pad, ...)
+            N, H, W, C, K, R, S, st, pad = a[3:12]
+            Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - S) // st + 1
+            return 2.0 * N * Ho * Wo * K * R * S * C
+
+        def lin_flops(a):  # fwd: (x,w,b,y,M,N,K,...); dgrad: (dy,w,dx,M,N,K,...); wgrad: (x,dy,dw,M,N,K,...)
+            return None
+
+        wrap("conv2d_fwd", conv_flops)
+        wrap("conv2d_dgrad", conv_flops)
+        wrap("conv2d_wgrad", conv_flops)
+        wrap("linear_fwd", lambda a: 2.0 * a[4] * a[5] * a[6])
+        wrap("linear_dgrad", lambda a: 2.0 * a[3] * a[4] * a[5])
+        wrap("linear_wgrad", lambda a: 2.0 * a[3] * a[4] * a[5])
+
+    def uninstall(self):
+        from deepsense6g_tii_amd._lib import lib
+        for name, orig in self._orig.items():
+            setattr(lib(), name, orig)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for var, fl, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            d = agg.setdefault(var, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += fl
+            d[2] += ms
+        return agg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (sequences)")
+    ap.add_argument("--ema", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=12)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    from deepsense6g_tii_amd import dist as ddist
+    from deepsense6g_tii_amd.model import GlobalConfig, TransFuser
+    from deepsense6g_tii_amd.synthetic import make_batch
+    from deepsense6g_tii_amd.train import EMA, FusedAdamW, train_iteration
+
+    rank, world, local = ddist.init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg = GlobalConfig()
+    torch.manual_seed(100)  # reference seeds everything with 100 (train2_seq.py:430-437)
+    model = TransFuser(cfg, dev)
+    model.train()
+    opt = FusedAdamW(model, lr=1e-4, ema_decay=0.999 if args.ema else None)
+    ema = None
+    if args.ema:
+        ema = EMA(model, 0.999, opt)
+        ema.register()
+    reducer = None
+    if world > 1:
+        ddist.broadcast_parameters(model)
+        reducer = ddist.attach(model, opt)
+    fronts, lidars, radars, gps, target, _ = make_batch(args.batch, cfg.seq_len, cfg.n_views, cfg.add_velocity,
+                                                        seed=100 + rank, device=dev)
+    batch = (fronts, lidars, radars, gps, target)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss, _ = train_iteration(model, opt, batch, ema, reducer)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = train_iteration(model, opt, batch, ema, reducer)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    # ---- roofline of the dominant kernel: one extra instrumented step (not part of the timed region) ----
+    roof = None
+    timer = IgemmTimer()
+    timer.install()
+    try:
+        train_iteration(model, opt, batch, ema, reducer)
+        agg = timer.summary()
+    finally:
+        timer.uninstall()
+    if agg:
+        dom = max(agg, key=lambda v: agg[v][2])
+        cnt, fl, ms = agg[dom]
+        tot_ms = sum(v[2] for v in agg.values())
+        tot_fl = sum(v[1] for v in agg.values())
+        roof = dict(bound="mfma", kernel=f"igemm_kernel<{MODE_NAMES[dom // 10]},{VARIANT_NAMES[dom % 10]}>",
+                    achieved=fl / (ms * 1e-3) / 1e12, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, traffic=None,
+                    launches_per_step=cnt, avg_launch_us=ms * 1e3 / cnt, flops_per_launch=fl / cnt,
+                    igemm_family=dict(achieved=tot_fl / (tot_ms * 1e-3) / 1e12, ms_per_step=tot_ms,
+                                      flops_per_step=tot_fl,
+                                      by_variant={f"{MODE_NAMES[v // 10]}/{VARIANT_NAMES[v % 10]}":
+                                                  dict(launches=a[0], ms=round(a[2], 3),
+                                                       tflops=round(a[1] / (a[2] * 1e-3) / 1e12, 2))
+                                                  for v, a in sorted(agg.items())}))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_batch, args.cpu_steps)
+
+    if rank == 0:
+        samples = args.batch * world * args.steps
+        value = samples / elapsed
+        out = {
+            "metric": "training samples/sec (5-frame seq, bs=12 per GPU)",
+            "value": value,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: full camera+LiDAR+radar+GPS fusion, 5x(3+1+2)x256x256 + 2x2 "
+                                   "GPS per sample, bs=12 per GPU, sigmoid focal loss, AdamW, train-mode BN, dropout 0.1",
+                       "global_batch": args.batch * world, "seq_len": cfg.seq_len,
+                       "parallelism": f"dp{world}", "ema": bool(args.ema)},
+            "loss": final_loss,
+            "algorithmic_gflop_per_sample": 559.3,
+            "model_tflops": value * 559.3e9 / 1e12,
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["gpu_over_cpu"] = value / cpu["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+"""ctypes binding of libds6g.so (the gfx950 kernel library).
+
+The prototypes are parsed from include/ds6g.h so the Python binding can never drift from the
+C ABI.  There is NO fallback: if the shared library is missing or does not export a declared
+symbol, importing / calling raises - the product path never runs on anything but the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+# torch bundles its own HIP runtime (same soname as /opt/rocm's libamdhip64.so.7).  It must be loaded
+# FIRST so that libds6g.so binds to the very runtime instance that owns torch's streams and allocations;
+# loaded the other way round the process holds two runtimes and every launch on a torch stream fails.
+import torch  # noqa: F401
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG_DIR)
+HEADER = os.path.join(_ROOT, "include", "ds6g.h")
+LIB_PATH = os.path.join(_PKG_DIR, "libds6g.so")
+
+_CTYPES = {
+    "int": ctypes.c_int,
+    "long": ctypes.c_long,
+    "size_t": ctypes.c_size_t,
+    "uint64_t": ctypes.c_uint64,
+    "float": ctypes.c_float,
+}
+
+
+class Ds6gError(RuntimeError):
+    pass
+
+
+def parse_header(path: str = HEADER):
+    """-> {name: (restype, [argtypes])} for every prototype in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|size_t)\s+(ds6g_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    ty = a.replace("const", "").split()[0]
+                    argtypes.append(_CTYPES[ty])
+        protos[name] = (_CTYPES[ret], argtypes)
+    return protos
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise Ds6gError(
+                f"{LIB_PATH} not found: build it with `make -C deepsense6g_tii_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback")
+        self._dll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        for name, (restype, argtypes) in self.protos.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError as e:
+                raise Ds6gError(f"libds6g.so does not export {name} declared in include/ds6g.h") from e
+            fn.restype = restype
+            fn.argtypes = argtypes
+            if restype is ctypes.c_int and name not in ("ds6g_version", "ds6g_last_igemm_variant"):
+                setattr(self, name[len("ds6g_"):], self._checked(fn, name))
+            else:
+                setattr(self, name[len("ds6g_"):], fn)
+
+    @staticmethod
+    def _checked(fn, name):
+        def call(*args):
+            rc = fn(*args)
+            if rc != 0:
+                raise Ds6gError(f"{name} failed with code {rc}")
+        call.__name__ = name
+        return call
+
+
+_LIB = None
+
+
+def lib() -> _Lib:
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib()
+    return _LIB

@@ -1,0 +1,81 @@
+// Shared device/host helpers for the gfx950 kernel library (libds6g.so).
+// All activations are fp32 NHWC in HBM; tokens are (B, T, C) row-major.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define DS6G_OK 0
+#define DS6G_ERR_ARG 1
+#define DS6G_ERR_LAUNCH 2
+#define DS6G_ERR_WORKSPACE 3
+
+#define DS6G_CHECK_ARG(cond)                                                                   \
+    do {                                                                                       \
+        if (!(cond)) {                                                                         \
+            fprintf(stderr, "[ds6g] bad argument: %s (%s:%d)\n", #cond, __FILE__, __LINE__);   \
+            return DS6G_ERR_ARG;                                                               \
+        }                                                                                      \
+    } while (0)
+
+// hipGetLastError() is sticky per thread: a benign failure inside the caller's runtime (e.g. PyTorch probing a
+// host pointer) would otherwise be reported by our next launch check.  Every entry point clears it first.
+#define DS6G_ENTER() (void)hipGetLastError()
+
+#define DS6G_LAUNCH_CHECK()                                                                    \
+    do {                                                                                       \
+        hipError_t e_ = hipGetLastError();                                                     \
+        if (e_ != hipSuccess) {                                                                \
+            fprintf(stderr, "[ds6g] launch failed: %s (%s:%d)\n", hipGetErrorString(e_),       \
+                    __FILE__, __LINE__);                                                       \
+            return DS6G_ERR_LAUNCH;                                                            \
+        }                                                                                      \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Counter-based dropout RNG: keep(idx) is a pure function of (seed, idx), so backward kernels
+// regenerate the mask instead of storing it.  Two rounds of a 32-bit integer finalizer over the
+// 64-bit counter mixed with the seed.
+__host__ __device__ __forceinline__ uint32_t ds6g_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t ds6g_rand_u32(uint64_t seed, uint64_t idx) {
+    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+    uint32_t h = ds6g_hash32(lo ^ s0);
+    h = ds6g_hash32(h ^ hi ^ (s1 * 0x9E3779B9U) ^ 0x85ebca6bU);
+    return h;
+}
+// threshold = floor(p * 2^32); element is DROPPED when rand < threshold.
+__host__ __device__ __forceinline__ bool ds6g_keep(uint64_t seed, uint64_t idx, uint32_t threshold) {
+    return ds6g_rand_u32(seed, idx) >= threshold;
+}
+static inline uint32_t ds6g_drop_threshold(float p) {
+    if (p <= 0.f) return 0u;
+    double t = (double)p * 4294967296.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_reduce_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

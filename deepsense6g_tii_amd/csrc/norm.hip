@@ -1,0 +1,461 @@
+// Train-mode BatchNorm2d (+ReLU, +residual) and LayerNorm, forward and backward, on fp32
+// channels-last rows ([M][C], C contiguous).  HBM-bound kernels: 16-B accesses per lane,
+// per-thread fp32 partials over <=64 rows, fp64 above that (no E[x^2]-E[x]^2 cancellation
+// problem and no float atomics: results are bitwise reproducible).
+// Reference call sites: torchvision BasicBlock BN via model2_seq.py:496,501,506,510-512,
+// 528-530,546-548,565-567 (train mode: batch mean / biased var, eps 1e-5, momentum .1 with
+// unbiased running_var); LayerNorm model2_seq.py:118-119,131-132,199,274 (eps 1e-5).
+#include "common.h"
+
+namespace {
+
+constexpr int BN_ROWS_PER_THREAD = 64;
+
+// partial[blk][0][c] = sum_rows a(r,c), partial[blk][1][c] = sum_rows b(r,c) in fp64.
+// MODE 0: a = x, b = x*x.   MODE 1: a = dyeff, b = dyeff * xhat  (BN backward)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ y_mask,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, long M, int C,
+                                                        int rows_per_block, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) double red[];  // [rowlanes][2][C]
+    const int cg = C >> 2;
+    const int colg = threadIdx.x % cg;
+    const int rowlane = threadIdx.x / cg;
+    const int rowlanes = 256 / cg;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
+    if (MODE == 1) {
+        mu = *reinterpret_cast<const f32x4*>(mean + colg * 4);
+        is = *reinterpret_cast<const f32x4*>(invstd + colg * 4);
+    }
+    for (long r = r0 + rowlane; r < r1; r += rowlanes) {
+        const size_t o = (size_t)r * C + colg * 4;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
+        if (MODE == 0) {
+            s1 += xv;
+            s2 += xv * xv;
+        } else {
+            f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+            if (y_mask) {
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(y_mask + o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+            }
+            s1 += g;
+            s2 += g * ((xv - mu) * is);
+        }
+    }
+    double* mine = red + ((size_t)rowlane * 2) * C + colg * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mine[j] = (double)s1[j];
+        mine[C + j] = (double)s2[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        double acc = 0.0;
+        for (int rl = 0; rl < rowlanes; ++rl) acc += red[(size_t)rl * 2 * C + i];
+        partial[(size_t)blockIdx.x * 2 * C + i] = acc;
+    }
+}
+
+// training statistics: mean / invstd from partials, running-stat update
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int nblk, long M, int C, float eps,
+                                         float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += partial[(size_t)b * 2 * C + c];
+        q += partial[(size_t)b * 2 * C + C + c];
+    }
+    const double mu = s / (double)M;
+    double var = q / (double)M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+}
+
+__global__ void bn_eval_prepare_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                       int C, float eps, float* __restrict__ mean, float* __restrict__ invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = running_mean[c];
+    invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+
+// y = relu?( (x - mean) * invstd * gamma + beta + residual? )
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       const float* __restrict__ residual, float* __restrict__ y,
+                                                       long total4, int C, int relu) {
+    const int cg = C >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % cg) * 4;
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        v = (v - mu) * is * g + b;
+        if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    }
+}
+
+// dgamma/dbeta and the per-channel coefficients of dx = a * (dyeff - b - xhat * cc)
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, long M, int C,
+                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ coef, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += partial[(size_t)b * 2 * C + c];
+        s2 += partial[(size_t)b * 2 * C + C + c];
+    }
+    if (accumulate) {
+        dgamma[c] += (float)s2;
+        dbeta[c] += (float)s1;
+    } else {
+        dgamma[c] = (float)s2;
+        dbeta[c] = (float)s1;
+    }
+    coef[c] = gamma[c] * invstd[c];
+    coef[C + c] = (float)(s1 / (double)M);
+    coef[2 * C + c] = (float)(s2 / (double)M);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy,
+                                                           const float* __restrict__ y_mask,
+                                                           const float* __restrict__ x,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ coef, float* __restrict__ dx,
+                                                           float* __restrict__ dres, long total4, int C) {
+    const int cg = C >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % cg) * 4;
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(coef + c4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(coef + C + c4);
+        const f32x4 cc = *reinterpret_cast<const f32x4*>(coef + 2 * C + c4);
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
+        if (y_mask) {
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(y_mask + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+        }
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + i * 4) - mu) * is;
+        if (dres) *reinterpret_cast<f32x4*>(dres + i * 4) = g;
+        *reinterpret_cast<f32x4*>(dx + i * 4) = a * (g - b - xh * cc);
+    }
+}
+
+int bn_geometry(long M, int C, int* rows_per_block, int* nblk) {
+    const int cg = C / 4;
+    if (C % 4 != 0 || cg > 256 || 256 % cg != 0) return DS6G_ERR_ARG;
+    *rows_per_block = BN_ROWS_PER_THREAD * (256 / cg);
+    *nblk = cdiv(M, *rows_per_block);
+    return DS6G_OK;
+}
+
+// ------------------------------------ LayerNorm ----------------------------------------------
+// one wave per row, lane owns columns lane + 64 j  (C <= 512, C % 64 == 0)
+template <int NJ>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M,
+                                                     float eps) {
+    constexpr int C = NJ * 64;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * C;
+    float v[NJ];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        v[j] = xr[lane + 64 * j];
+        s += v[j];
+    }
+    const float mu = wave_reduce_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const float d = v[j] - mu;
+        q += d * d;
+    }
+    const float rs = 1.0f / sqrtf(wave_reduce_sum(q) * (1.0f / C) + eps);
+    float* yr = y + (size_t)row * C;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = lane + 64 * j;
+        yr[c] = (v[j] - mu) * rs * gamma[c] + beta[c];
+    }
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+}
+
+constexpr int LN_BWD_ROWS = 64;  // rows per block (16 per wave)
+
+template <int NJ>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ add,
+                                                     float* __restrict__ dx, float* __restrict__ partial, int M) {
+    constexpr int C = NJ * 64;
+    __shared__ float red[4][2][C];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float g[NJ], dg[NJ], db[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        g[j] = gamma[lane + 64 * j];
+        dg[j] = 0.f;
+        db[j] = 0.f;
+    }
+    const int rbase = blockIdx.x * LN_BWD_ROWS + wave * (LN_BWD_ROWS / 4);
+    for (int rr = 0; rr < LN_BWD_ROWS / 4; ++rr) {
+        const int row = rbase + rr;
+        if (row >= M) break;
+        const size_t o = (size_t)row * C;
+        const float mu = mean[row], rs = rstd[row];
+        float dyv[NJ], xh[NJ];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = lane + 64 * j;
+            dyv[j] = dy[o + c];
+            xh[j] = (x[o + c] - mu) * rs;
+            const float t = dyv[j] * g[j];
+            s1 += t;
+            s2 += t * xh[j];
+            dg[j] += dyv[j] * xh[j];
+            db[j] += dyv[j];
+        }
+        s1 = wave_reduce_sum(s1) * (1.0f / C);
+        s2 = wave_reduce_sum(s2) * (1.0f / C);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = lane + 64 * j;
+            float v = rs * (dyv[j] * g[j] - s1 - xh[j] * s2);
+            if (add) v += add[o + c];
+            dx[o + c] = v;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        red[wave][0][lane + 64 * j] = dg[j];
+        red[wave][1][lane + 64 * j] = db[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i % C;
+        partial[(size_t)blockIdx.x * 2 * C + i] =
+            red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+    }
+}
+
+// out[c] (+)= sum_b partial[b][c]   (generic column finalize over row-block partials)
+__global__ void col_finalize_kernel(const float* __restrict__ partial, int nblk, int ncol, float* __restrict__ out0,
+                                    float* __restrict__ out1, int split_at, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * ncol + c];
+    float* dst = (c < split_at) ? (out0 + c) : (out1 + (c - split_at));
+    *dst = accumulate ? (*dst + (float)s) : (float)s;
+}
+
+// partial[blk][c] = sum over the block's rows of x[r][c]   (bias gradients, pos_emb gradient)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long M, int C,
+                                                             int rows_per_block, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float redf[];  // [rowlanes][C]
+    const int cg = C >> 2;
+    const int cols_per_pass = min(cg, 256);
+    const int rowlanes = 256 / cols_per_pass;
+    const int rowlane = threadIdx.x / cols_per_pass;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    for (int cbase = 0; cbase < cg; cbase += cols_per_pass) {
+        const int colg = cbase + threadIdx.x % cols_per_pass;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (colg < cg)
+            for (long r = r0 + rowlane; r < r1; r += rowlanes) s += *reinterpret_cast<const f32x4*>(x + (size_t)r * C + colg * 4);
+        if (colg < cg) *reinterpret_cast<f32x4*>(redf + (size_t)rowlane * C + colg * 4) = s;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.f;
+        for (int rl = 0; rl < rowlanes; ++rl) acc += redf[(size_t)rl * C + c];
+        partial[(size_t)blockIdx.x * C + c] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ds6g_bn_workspace_bytes(long M, int C) {
+    int rpb, nblk;
+    if (bn_geometry(M, C, &rpb, &nblk)) return 0;
+    return (size_t)nblk * 2 * C * sizeof(double) + 3 * (size_t)C * sizeof(float);
+}
+
+// training-mode statistics of x[M][C]; updates running stats in place when given
+int ds6g_bn_stats(const float* x, long M, int C, float eps, float momentum, float* mean, float* invstd,
+                  float* running_mean, float* running_var, void* ws, size_t ws_bytes, void* stream) {
+    DS6G_ENTER();
+    int rpb, nblk;
+    DS6G_CHECK_ARG(x && mean && invstd && ws && M > 0);
+    DS6G_CHECK_ARG(bn_geometry(M, C, &rpb, &nblk) == DS6G_OK);
+    DS6G_CHECK_ARG(ws_bytes >= ds6g_bn_workspace_bytes(M, C));
+    double* partial = (double*)ws;
+    const size_t lds = (size_t)(256 / (C / 4)) * 2 * C * sizeof(double);
+    hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, x, nullptr, nullptr,
+                       nullptr, nullptr, M, C, rpb, partial);
+    DS6G_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, nblk,
+                       M, C, eps, momentum, mean, invstd, running_mean, running_var);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+int ds6g_bn_eval_prepare(const float* running_mean, const float* running_var, int C, float eps, float* mean,
+                         float* invstd, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(running_mean && running_var && mean && invstd);
+    hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, running_mean,
+                       running_var, C, eps, mean, invstd);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+int ds6g_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                  const float* residual, float* y, long M, int C, int relu, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && mean && invstd && gamma && beta && y && C % 4 == 0);
+    const long total4 = M * C / 4;
+    const int grid = (int)min((long)8192, (total4 + 255) / 256);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta,
+                       residual, y, total4, C, relu);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+// dyeff = dy * (y_mask > 0) (y_mask nullable); dx = gamma*invstd*(dyeff - mean(dyeff) - xhat*mean(dyeff*xhat));
+// dgamma/dbeta (+)=; dres (nullable) receives dyeff (gradient of the residual branch)
+int ds6g_bn_bwd(const float* dy, const float* y_mask, const float* x, const float* mean, const float* invstd,
+                const float* gamma, float* dx, float* dgamma, float* dbeta, float* dres, long M, int C,
+                int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream) {
+    DS6G_ENTER();
+    int rpb, nblk;
+    DS6G_CHECK_ARG(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && ws);
+    DS6G_CHECK_ARG(bn_geometry(M, C, &rpb, &nblk) == DS6G_OK);
+    DS6G_CHECK_ARG(ws_bytes >= ds6g_bn_workspace_bytes(M, C));
+    double* partial = (double*)ws;
+    float* coef = (float*)((char*)ws + (size_t)nblk * 2 * C * sizeof(double));
+    const size_t lds = (size_t)(256 / (C / 4)) * 2 * C * sizeof(double);
+    hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, x, dy, y_mask, mean,
+                       invstd, M, C, rpb, partial);
+    DS6G_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, nblk, M,
+                       C, gamma, invstd, dgamma, dbeta, coef, accumulate_param_grads);
+    DS6G_LAUNCH_CHECK();
+    const long total4 = M * C / 4;
+    const int grid = (int)min((long)8192, (total4 + 255) / 256);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, y_mask, x, mean,
+                       invstd, coef, dx, dres, total4, C);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+int ds6g_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                       int M, int C, float eps, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && gamma && beta && y && mean && rstd && M > 0);
+    DS6G_CHECK_ARG(C % 64 == 0 && C <= 512);
+    dim3 grid(cdiv(M, 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (C / 64) {
+        case 1: hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
+        case 2: hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
+        case 4: hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
+        case 8: hipLaunchKernelGGL((ln_fwd_kernel<8>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
+        default: DS6G_CHECK_ARG(!"LayerNorm width must be 64/128/256/512");
+    }
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+size_t ds6g_layernorm_bwd_workspace_bytes(int M, int C) { return (size_t)cdiv(M, LN_BWD_ROWS) * 2 * C * sizeof(float); }
+
+// dx = add? + LN'(dy); dgamma/dbeta (+)=
+int ds6g_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* add, float* dx, float* dgamma, float* dbeta, int M, int C,
+                       int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws);
+    DS6G_CHECK_ARG(C % 64 == 0 && C <= 512);
+    DS6G_CHECK_ARG(ws_bytes >= ds6g_layernorm_bwd_workspace_bytes(M, C));
+    const int nblk = cdiv(M, LN_BWD_ROWS);
+    float* partial = (float*)ws;
+    dim3 grid(nblk), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (C / 64) {
+        case 1: hipLaunchKernelGGL((ln_bwd_kernel<1>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M); break;
+        case 2: hipLaunchKernelGGL((ln_bwd_kernel<2>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M); break;
+        case 4: hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M); break;
+        case 8: hipLaunchKernelGGL((ln_bwd_kernel<8>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M); break;
+        default: DS6G_CHECK_ARG(!"LayerNorm width must be 64/128/256/512");
+    }
+    DS6G_LAUNCH_CHECK();
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(cdiv(2 * C, 64)), dim3(64), 0, st, partial, nblk, 2 * C, dgamma,
+                       dbeta, C, accumulate_param_grads);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+size_t ds6g_colsum_workspace_bytes(long M, int C) { return (size_t)cdiv(M, 256) * C * sizeof(float); }
+
+// out[c] (+)= sum_r x[r][c]
+int ds6g_colsum(const float* x, long M, int C, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && out && ws && C % 4 == 0 && M > 0);
+    DS6G_CHECK_ARG(ws_bytes >= ds6g_colsum_workspace_bytes(M, C));
+    const int rpb = 256;
+    const int nblk = cdiv(M, rpb);
+    const int cols_per_pass = (C / 4) < 256 ? (C / 4) : 256;
+    DS6G_CHECK_ARG(256 % cols_per_pass == 0);
+    const size_t lds = (size_t)(256 / cols_per_pass) * C * sizeof(float);
+    float* partial = (float*)ws;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), lds, (hipStream_t)stream, x, M, C, rpb, partial);
+    DS6G_LAUNCH_CHECK();
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, nblk, C, out,
+                       out, C, accumulate);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+// Training-step kernels around the fusion model (fp32):
+//   sigmoid focal loss on soft targets, fused forward + gradient   train2_seq.py:291-301
+//   AdamW (decoupled wd) + EMA shadow update over a flat arena      train2_seq.py:131-134,315-320,539
+//   tiny Linear layers (GPS embedding chain, join MLP; M <= 64)     model2_seq.py:422-425,863-869
+// The optimizer is HBM-bound: one pass reads p,g,m,v(,shadow) and writes p,m,v(,shadow) with
+// 16-B accesses; algorithmic traffic 28 B/param (+12 B/param with EMA).
+#include "common.h"
+
+namespace {
+
+// loss = mean_i ce_i (1-p_t)^gamma (alpha t + (1-alpha)(1-t));  dlogits_i = dloss/dx_i * upstream
+__global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                    float* __restrict__ loss, float* __restrict__ dx, int n,
+                                                    float alpha, float gamma, float upstream) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const float inv_n = 1.0f / (float)n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float xi = x[i], ti = t[i];
+        const float p = 1.0f / (1.0f + expf(-xi));
+        // BCE-with-logits, numerically stable: max(x,0) - x t + log(1 + exp(-|x|))
+        const float ce = fmaxf(xi, 0.f) - xi * ti + log1pf(expf(-fabsf(xi)));
+        const float pt = p * ti + (1.f - p) * (1.f - ti);
+        const float om = 1.f - pt;
+        const float at = alpha >= 0.f ? alpha * ti + (1.f - alpha) * (1.f - ti) : 1.f;
+        const float mod = powf(om, gamma);
+        acc += at * ce * mod;
+        if (dx) {
+            // d ce/dx = p - t ; d pt/dx = (2t-1) p (1-p) ; d mod/dx = -gamma om^(gamma-1) dpt/dx
+            const float dpt = (2.f * ti - 1.f) * p * (1.f - p);
+            const float dmod = om > 0.f ? -gamma * powf(om, gamma - 1.f) * dpt : 0.f;
+            dx[i] = at * ((p - ti) * mod + ce * dmod) * inv_n * upstream;
+        }
+    }
+    acc = wave_reduce_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss = (red[0] + red[1] + red[2] + red[3]) * inv_n;
+}
+
+struct AdamArgs {
+    float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, ema_decay, grad_scale;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    float* __restrict__ shadow, long n4, AdamArgs a) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 pv = *reinterpret_cast<f32x4*>(p + i * 4);
+        const f32x4 gv = a.grad_scale * *reinterpret_cast<const f32x4*>(g + i * 4);
+        f32x4 mv = *reinterpret_cast<f32x4*>(m + i * 4);
+        f32x4 vv = *reinterpret_cast<f32x4*>(v + i * 4);
+        pv *= (1.f - a.lr * a.wd);
+        mv = a.beta1 * mv + (1.f - a.beta1) * gv;
+        vv = a.beta2 * vv + (1.f - a.beta2) * gv * gv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float denom = sqrtf(vv[j]) / a.bc2_sqrt + a.eps;
+            pv[j] -= (a.lr / a.bc1) * (mv[j] / denom);
+        }
+        *reinterpret_cast<f32x4*>(p + i * 4) = pv;
+        *reinterpret_cast<f32x4*>(m + i * 4) = mv;
+        *reinterpret_cast<f32x4*>(v + i * 4) = vv;
+        if (shadow) {
+            f32x4 sv = *reinterpret_cast<f32x4*>(shadow + i * 4);
+            sv = (1.f - a.ema_decay) * pv + a.ema_decay * sv;
+            *reinterpret_cast<f32x4*>(shadow + i * 4) = sv;
+        }
+    }
+}
+
+// y[m][n] = act( sum_k x[row(m)][k] w[n][k] + b[n] ), row(m) = (m / rpg) * gstride + (m % rpg) * K
+__global__ void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                        const float* __restrict__ b, float* __restrict__ y, int M, int N, int K,
+                                        int rpg, long gstride, int relu) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * N) return;
+    const int n = i % N, m = i / N;
+    const float* xr = x + (long)(m / rpg) * gstride + (long)(m % rpg) * K;
+    const float* wr = w + (long)n * K;
+    float s = b ? b[n] : 0.f;
+    for (int k = 0; k < K; ++k) s = fmaf(xr[k], wr[k], s);
+    y[i] = relu ? fmaxf(s, 0.f) : s;
+}
+
+// dyeff = dy * (y_mask > 0); dx[row(m)][k] (+)= sum_n dyeff[m][n] w[n][k]
+__global__ void small_linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ y_mask,
+                                          const float* __restrict__ w, float* __restrict__ dx, int M, int N, int K,
+                                          int rpg, long gstride, int accumulate) {  // rpg/gstride address dx
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * K) return;
+    const int k = i % K, m = i / K;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) {
+        float g = dy[(long)m * N + n];
+        if (y_mask && !(y_mask[(long)m * N + n] > 0.f)) g = 0.f;
+        s = fmaf(g, w[(long)n * K + k], s);
+    }
+    float* d = dx + (long)(m / rpg) * gstride + (long)(m % rpg) * K + k;
+    *d = accumulate ? *d + s : s;
+}
+
+// dw[n][k] (+)= sum_m dyeff[m][n] x[row(m)][k];  db[n] (+)= sum_m dyeff[m][n]
+__global__ void small_linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ y_mask,
+                                          const float* __restrict__ x, float* __restrict__ dw,
+                                          float* __restrict__ db, int M, int N, int K, int rpg, long gstride,
+                                          int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * (K + 1)) return;
+    const int k = i % (K + 1), n = i / (K + 1);
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) {
+        float g = dy[(long)m * N + n];
+        if (y_mask && !(y_mask[(long)m * N + n] > 0.f)) g = 0.f;
+        const float xv = (k < K) ? x[(long)(m / rpg) * gstride + (long)(m % rpg) * K + k] : 1.f;
+        s = fmaf(g, xv, s);
+    }
+    float* d = (k < K) ? (dw + (long)n * K + k) : (db + n);
+    *d = accumulate ? *d + s : s;
+}
+
+}  // namespace
+
+extern "C" {
+
+// loss (1 float) and, when dlogits != NULL, dlogits = upstream * dloss/dlogits.  n = B*64 elements.
+int ds6g_focal_loss(const float* logits, const float* target, float* loss, float* dlogits, int n, float alpha,
+                    float gamma, float upstream, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(logits && target && loss && n > 0);
+    hipLaunchKernelGGL(focal_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, loss, dlogits, n,
+                       alpha, gamma, upstream);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+// one AdamW step (torch semantics: decoupled weight decay, bias correction, eps outside the sqrt
+// scaling) over n contiguous floats; step is 1-based.  grad_scale multiplies g first (1/world for DP).
+// shadow != NULL also does the EMA update shadow = (1-d) p_new + d shadow.
+int ds6g_adamw_step(float* p, const float* g, float* m, float* v, float* shadow, long n, int step, float lr,
+                    float beta1, float beta2, float eps, float wd, float ema_decay, float grad_scale, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(p && g && m && v && n % 4 == 0 && step >= 1);
+    AdamArgs a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd;
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    a.ema_decay = ema_decay; a.grad_scale = grad_scale;
+    const long n4 = n / 4;
+    const int grid = (int)(n4 + 255) / 256 < 4096 ? (int)((n4 + 255) / 256) : 4096;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, shadow, n4, a);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+// x rows are addressed in groups: row m lives at x + (m / rows_per_group) * group_stride + (m % rows_per_group) * K
+// (dense input: rows_per_group = M, group_stride = 0)
+int ds6g_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K,
+                          int rows_per_group, long group_stride, int relu, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && w && y && rows_per_group > 0);
+    hipLaunchKernelGGL(small_linear_fwd_kernel, dim3(cdiv((long)M * N, 256)), dim3(256), 0, (hipStream_t)stream, x, w,
+                       b, y, M, N, K, rows_per_group, group_stride, relu);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+// dx (nullable) has its own row addressing (dx_rows_per_group, dx_group_stride)
+int ds6g_small_linear_bwd(const float* dy, const float* y_mask, const float* x, const float* w, float* dx, float* dw,
+                          float* db, int M, int N, int K, int rows_per_group, long group_stride,
+                          int dx_rows_per_group, long dx_group_stride, int accumulate_dx, int accumulate_params,
+                          void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(dy && x && w && dw && db && rows_per_group > 0);
+    if (dx) {
+        DS6G_CHECK_ARG(dx_rows_per_group > 0);
+        hipLaunchKernelGGL(small_linear_dgrad_kernel, dim3(cdiv((long)M * K, 256)), dim3(256), 0, (hipStream_t)stream,
+                           dy, y_mask, w, dx, M, N, K, dx_rows_per_group, dx_group_stride, accumulate_dx);
+        DS6G_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(small_linear_wgrad_kernel, dim3(cdiv((long)N * (K + 1), 256)), dim3(256), 0,
+                       (hipStream_t)stream, dy, y_mask, x, dw, db, M, N, K, rows_per_group, group_stride,
+                       accumulate_params);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+int ds6g_version(void) { return 1; }
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+"""Data parallelism for the fusion path: one process per GPU, gradients summed with RCCL
+(torch.distributed backend "nccl" on ROCm) over xGMI.
+
+The reference uses single-process torch.nn.DataParallel (train2_seq.py:538): per-step parameter
+broadcast, input scatter, output gather, gradient reduce onto device 0.  Here each rank owns its
+minibatch shard (per-rank BatchNorm statistics, as in DataParallel replicas) and the only exchange
+is one gradient sum per step.  Because the gradient arena is laid out in backward-completion order
+(model.TransFuser._milestone) the finished gradients are always a contiguous prefix of it, so a
+bucket is a plain slice: no packing copy, and each all-reduce is issued the moment its slice is
+final, overlapping the rest of the backward walk.  xGMI is point-to-point (7 links x ~153 GB/s per
+GPU), so buckets are kept large (>= ~32 MB: ring all-reduce is per-link bandwidth bound, small
+messages are latency bound): milestones are coalesced until a bucket reaches `min_bucket_elems`.
+The 1/world average is folded into the optimizer kernel (FusedAdamW.grad_scale).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialise from torchrun-style env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).  Returns (rank, world, local)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class GradReducer:
+    """Sums a flat gradient buffer across ranks in contiguous buckets as they become final.
+
+    grad_flat: 1-D tensor (the gradient arena).  `ready(k, lo, hi)` is called by the backward walk
+    when grad_flat[lo:hi] is final (milestones arrive in increasing offset order).  `finish()` flushes
+    the tail and makes the current stream wait for every outstanding all-reduce."""
+
+    def __init__(self, grad_flat, group=None, min_bucket_elems=8 << 20):
+        self.g = grad_flat
+        self.group = group
+        self.min_bucket = int(min_bucket_elems)
+        self.works = []
+        self.lo = 0
+        self.hi = 0
+        self.issued = []  # (lo, hi) of every bucket this step, for tests / logging
+
+    @property
+    def world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def begin(self):
+        self.works, self.issued = [], []
+        self.lo = self.hi = 0
+
+    def ready(self, k, lo, hi):
+        assert lo == self.hi, "gradient milestones must arrive as a contiguous, growing prefix"
+        self.hi = hi
+        if self.hi - self.lo >= self.min_bucket:
+            self._flush()
+
+    def _flush(self):
+        if self.hi > self.lo:
+            if self.world > 1:
+                self.works.append(dist.all_reduce(self.g[self.lo:self.hi], op=dist.ReduceOp.SUM, group=self.group,
+                                                  async_op=True))
+            self.issued.append((self.lo, self.hi))
+            self.lo = self.hi
+
+    def finish(self):
+        self._flush()
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+def broadcast_parameters(model, src=0, group=None):
+    """One-time parameter (and BN buffer) broadcast at start-up; there is no per-step broadcast."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    p, _ = model.flat_parameters()
+    dist.broadcast(p, src=src, group=group)
+    for b in model.buffers():
+        dist.broadcast(b, src=src, group=group)
+
+
+def attach(model, optimizer, group=None, min_bucket_elems=8 << 20):
+    """Wire a GradReducer into the model's backward walk and fold the 1/world average into the optimizer."""
+    red = GradReducer(model.flat_parameters()[1], group, min_bucket_elems)
+    model.grad_ready_hook = red.ready
+    optimizer.grad_scale = 1.0 / red.world
+    return red

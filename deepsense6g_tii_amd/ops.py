@@ -1,0 +1,211 @@
+"""Thin tensor-level wrappers over the C ABI (include/ds6g.h).
+
+PyTorch is used for device memory and the current HIP stream only; every arithmetic operation is
+a kernel in libds6g.so.  Tensors must be fp32, contiguous, on a HIP device; shapes are checked here
+on the host because an out-of-bounds kernel can take the whole GPU node down.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import lib
+
+F32 = torch.float32
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, *shape):
+    assert t.dtype == F32 and t.is_cuda and t.is_contiguous(), (t.dtype, t.device, t.stride())
+    if shape:
+        assert tuple(t.shape) == tuple(shape), (tuple(t.shape), shape)
+
+
+class Workspace:
+    """One caller-owned scratch buffer shared by all kernels of a stream (split-K slabs, BN / LN /
+    column-sum partials).  Stream order makes the reuse safe."""
+
+    def __init__(self, device, nbytes=256 << 20):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.nbytes = nbytes
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+def conv_out_hw(H, W, R, S, stride, pad):
+    return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+
+
+def conv2d_fwd(x, w_ohwi_ptr, K, R, S, stride, pad, out=None):
+    N, H, W, C = x.shape
+    _chk(x)
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    y = out if out is not None else torch.empty((N, Ho, Wo, K), dtype=F32, device=x.device)
+    _chk(y, N, Ho, Wo, K)
+    lib().conv2d_fwd(_p(x), w_ohwi_ptr, _p(y), N, H, W, C, K, R, S, stride, pad, _stream())
+    return y
+
+
+def conv2d_dgrad(dy, w_ohwi_ptr, x_shape, R, S, stride, pad, out=None, accumulate=False):
+    N, H, W, C = x_shape
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    K = dy.shape[3]
+    _chk(dy, N, Ho, Wo, K)
+    dx = out if out is not None else torch.empty(x_shape, dtype=F32, device=dy.device)
+    _chk(dx, *x_shape)
+    lib().conv2d_dgrad(_p(dy), w_ohwi_ptr, _p(dx), N, H, W, C, K, R, S, stride, pad, int(accumulate), _stream())
+    return dx
+
+
+def conv2d_wgrad(x, dy, dw_ptr, R, S, stride, pad, ws: Workspace, accumulate=False):
+    N, H, W, C = x.shape
+    _chk(x)
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    K = dy.shape[3]
+    _chk(dy, N, Ho, Wo, K)
+    lib().conv2d_wgrad(_p(x), _p(dy), dw_ptr, N, H, W, C, K, R, S, stride, pad, int(accumulate), ws.ptr, ws.nbytes,
+                       _stream())
+
+
+def linear_fwd(x, w_ptr, b_ptr, N, relu=False, residual=None, drop_p=0.0, seed=0, seed_off=0, out=None):
+    M, K = x.shape
+    _chk(x)
+    y = out if out is not None else torch.empty((M, N), dtype=F32, device=x.device)
+    _chk(y, M, N)
+    if residual is not None:
+        _chk(residual, M, N)
+    lib().linear_fwd(_p(x), w_ptr, b_ptr, _p(y), M, N, K, int(relu), _p(residual), float(drop_p), seed, seed_off,
+                     _stream())
+    return y
+
+
+def linear_dgrad(dy, w_ptr, K, relu_mask_src=None, out=None, accumulate=False):
+    M, N = dy.shape
+    _chk(dy)
+    dx = out if out is not None else torch.empty((M, K), dtype=F32, device=dy.device)
+    _chk(dx, M, K)
+    if relu_mask_src is not None:
+        _chk(relu_mask_src, M, K)
+    lib().linear_dgrad(_p(dy), w_ptr, _p(dx), M, N, K, _p(relu_mask_src), int(accumulate), _stream())
+    return dx
+
+
+def linear_wgrad(x, dy, dw_ptr, ws: Workspace, accumulate=False):
+    M, K = x.shape
+    M2, N = dy.shape
+    assert M == M2
+    _chk(x)
+    _chk(dy)
+    lib().linear_wgrad(_p(x), _p(dy), dw_ptr, M, N, K, int(accumulate), ws.ptr, ws.nbytes, _stream())
+
+
+def colsum(x, out_ptr, ws: Workspace, accumulate=False):
+    M, C = x.shape
+    _chk(x)
+    lib().colsum(_p(x), M, C, out_ptr, int(accumulate), ws.ptr, ws.nbytes, _stream())
+
+
+# ------------------------------------------------------------------------------------------------
+def bn_stats(x2d_rows, C, x, mean, invstd, rm_ptr, rv_ptr, ws: Workspace, eps=1e-5, momentum=0.1):
+    lib().bn_stats(_p(x), x2d_rows, C, eps, momentum, _p(mean), _p(invstd), rm_ptr, rv_ptr, ws.ptr, ws.nbytes,
+                   _stream())
+
+
+def bn_eval_prepare(rm_ptr, rv_ptr, C, mean, invstd, eps=1e-5):
+    lib().bn_eval_prepare(rm_ptr, rv_ptr, C, eps, _p(mean), _p(invstd), _stream())
+
+
+def bn_apply(x, mean, invstd, gamma_ptr, beta_ptr, relu, residual=None, out=None):
+    _chk(x)
+    C = x.shape[-1]
+    M = x.numel() // C
+    y = out if out is not None else torch.empty_like(x)
+    if residual is not None:
+        _chk(residual, *x.shape)
+    lib().bn_apply(_p(x), _p(mean), _p(invstd), gamma_ptr, beta_ptr, _p(residual), _p(y), M, C, int(relu), _stream())
+    return y
+
+
+def bn_bwd(dy, y_mask, x, mean, invstd, gamma_ptr, dgamma_ptr, dbeta_ptr, ws: Workspace, want_dres=False,
+           accumulate=False, dx_out=None):
+    _chk(dy, *x.shape)
+    _chk(x)
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = dx_out if dx_out is not None else torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    lib().bn_bwd(_p(dy), _p(y_mask), _p(x), _p(mean), _p(invstd), gamma_ptr, _p(dx), dgamma_ptr, dbeta_ptr, _p(dres),
+                 M, C, int(accumulate), ws.ptr, ws.nbytes, _stream())
+    return dx, dres
+
+
+def layernorm_fwd(x, gamma_ptr, beta_ptr, eps=1e-5):
+    M, C = x.shape
+    _chk(x)
+    y = torch.empty_like(x)
+    mean = torch.empty(M, dtype=F32, device=x.device)
+    rstd = torch.empty(M, dtype=F32, device=x.device)
+    lib().layernorm_fwd(_p(x), gamma_ptr, beta_ptr, _p(y), _p(mean), _p(rstd), M, C, eps, _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma_ptr, dgamma_ptr, dbeta_ptr, ws: Workspace, add=None, accumulate=False,
+                  out=None):
+    M, C = x.shape
+    _chk(dy, M, C)
+    _chk(x)
+    dx = out if out is not None else torch.empty_like(x)
+    if add is not None:
+        _chk(add, M, C)
+    lib().layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), gamma_ptr, _p(add), _p(dx), dgamma_ptr, dbeta_ptr, M, C,
+                        int(accumulate), ws.ptr, ws.nbytes, _stream())
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+def attention_fwd(q, k, v, B, T, nh, drop_p=0.0, seed=0, seed_off=0):
+    M, C = q.shape
+    assert M == B * T
+    for t in (q, k, v):
+        _chk(t, M, C)
+    o = torch.empty_like(q)
+    lse = torch.empty((B, nh, T), dtype=F32, device=q.device)
+    lib().attention_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, T, nh, C // nh, C, float(drop_p), seed, seed_off,
+                        _stream())
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, d_o, lse, B, T, nh, drop_p=0.0, seed=0, seed_off=0):
+    M, C = q.shape
+    for t in (q, k, v, o, d_o):
+        _chk(t, M, C)
+    _chk(lse, B, nh, T)
+    delta = torch.empty_like(lse)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    lib().attention_bwd(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, T, nh,
+                        C // nh, C, float(drop_p), seed, seed_off, _stream())
+    return dq, dk, dv
+
+
+# ------------------------------------------------------------------------------------------------
+def dropout(src, drop_p, seed, seed_off, out=None):
+    _chk(src)
+    dst = out if out is not None else torch.empty_like(src)
+    lib().dropout(_p(src), _p(dst), src.numel(), float(drop_p), seed, seed_off, _stream())
+    return dst
+
+
+def axpby(a, b, alpha=1.0, beta=1.0, out=None):
+    _chk(a)
+    o = out if out is not None else torch.empty_like(a)
+    lib().axpby(_p(a), _p(b), _p(o), a.numel(), float(alpha), float(beta), _stream())
+    return o

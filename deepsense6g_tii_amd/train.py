@@ -1,0 +1,222 @@
+"""Training-step pieces around the fusion model, mirroring /root/reference/train2_seq.py:
+FocalLoss (:291-301), AdamW (:539) and EMA (:303-334) as fused HIP kernels over the flat
+parameter arena, the per-epoch cyclic-cosine LR schedule (scheduler.py:82-119 with the arguments of
+train2_seq.py:541-547), the top-k / DBA metrics (:347-383) and the per-iteration order of
+Engine.train (:94-157): zero_grad -> forward -> focal(soft target) -> backward -> step -> ema.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import lib
+
+F32 = torch.float32
+
+
+# ------------------------------------------------------------------------------------------------
+class _FocalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, alpha, gamma):
+        logits = logits.contiguous()
+        target = target.contiguous()
+        loss = torch.empty(1, dtype=F32, device=logits.device)
+        dlogits = torch.empty_like(logits)
+        lib().focal_loss(logits.data_ptr(), target.data_ptr(), loss.data_ptr(), dlogits.data_ptr(), logits.numel(),
+                         alpha, gamma, 1.0, ops._stream())
+        ctx.save_for_backward(dlogits)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        out = torch.empty_like(dlogits)
+        # dlogits * upstream through the library's axpby kernel (beta term unused)
+        if g.numel() == 1 and dlogits.numel() % 4 == 0:
+            lib().axpby(dlogits.data_ptr(), 0, out.data_ptr(), dlogits.numel(), float(g), 0.0, ops._stream())
+        else:  # pragma: no cover
+            raise RuntimeError("unexpected focal-loss upstream gradient")
+        return out, None, None, None
+
+
+class FocalLoss(nn.Module):
+    """train2_seq.py:291-301 (sigmoid focal loss, alpha .25, gamma 2, mean; 1-D integer targets are
+    one-hot encoded to 64 classes)."""
+
+    def __init__(self, gamma=2, alpha=0.25):
+        super().__init__()
+        self.gamma = gamma
+        self.alpha = alpha
+
+    def forward(self, input, target):
+        if target.dim() == 1:
+            target = torch.nn.functional.one_hot(target.long(), num_classes=64)
+        return _FocalFn.apply(input, target.to(input.device, F32), float(self.alpha), float(self.gamma))
+
+
+# ------------------------------------------------------------------------------------------------
+class FusedAdamW:
+    """torch.optim.AdamW(model.parameters(), lr) semantics (train2_seq.py:539: betas (.9,.999), eps 1e-8,
+    weight_decay .01 on every parameter) as ONE streaming kernel over the parameter arena, optionally
+    fused with the EMA shadow update (train2_seq.py:315-320)."""
+
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, ema_decay=None):
+        self.model = model
+        p, g = model.flat_parameters()
+        self.m = torch.zeros_like(p)
+        self.v = torch.zeros_like(p)
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
+        self.step_count = 0
+        self.ema_decay = ema_decay
+        self.shadow = p.clone() if ema_decay is not None else None
+        self.grad_scale = 1.0  # 1/world_size under data parallelism (sum all-reduce, scale here)
+
+    def zero_grad(self, set_to_none=True):
+        if set_to_none:
+            for p in self.model.parameters():
+                p.grad = None
+        else:
+            self.model.flat_parameters()[1].zero_()
+
+    def step(self):
+        if not self.model.params_in_arena():
+            raise RuntimeError("parameters were re-pointed away from the arena (EMA shadow applied?): restore first")
+        p, g = self.model.flat_parameters()
+        self.step_count += 1
+        grp = self.param_groups[0]
+        lib().adamw_step(p.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                         0 if self.shadow is None else self.shadow.data_ptr(), p.numel(), self.step_count,
+                         float(grp["lr"]), grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"],
+                         0.0 if self.ema_decay is None else float(self.ema_decay), float(self.grad_scale),
+                         ops._stream())
+
+    def state_dict(self):
+        return dict(m=self.m, v=self.v, step=self.step_count, shadow=self.shadow, param_groups=self.param_groups)
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.step_count = int(sd["step"])
+        if self.shadow is not None and sd.get("shadow") is not None:
+            self.shadow.copy_(sd["shadow"])
+
+
+class EMA:
+    """train2_seq.py:303-334 API (register / update / apply_shadow / restore) over a shadow arena.
+    apply_shadow re-points every ``param.data`` at its shadow view exactly as the reference does
+    (:326-327); the kernels read parameter pointers at call time, so evaluation then runs on the
+    averaged weights with no copy."""
+
+    def __init__(self, model, decay, optimizer: FusedAdamW | None = None):
+        self.model = model
+        self.decay = decay
+        self.optimizer = optimizer
+        self.shadow = None
+        self.backup = {}
+        self._views = None
+
+    def register(self):
+        if self.optimizer is not None and self.optimizer.shadow is not None:
+            self.shadow = self.optimizer.shadow  # updated inside the fused optimizer kernel
+        else:
+            self.shadow = self.model.flat_parameters()[0].clone()
+        self._views = {}
+        for name, p in self.model.named_parameters():
+            off, n = self.model._pslice[name]
+            seg = self.shadow[off:off + n]
+            if p.dim() == 4:
+                O, I, R, S = p.shape
+                self._views[name] = seg.view(O, R, S, I).permute(0, 3, 1, 2)
+            else:
+                self._views[name] = seg.view(p.shape)
+
+    def update(self):
+        if self.optimizer is not None and self.optimizer.shadow is self.shadow:
+            return  # already done by FusedAdamW.step()
+        p = self.model.flat_parameters()[0]
+        ops.axpby(p, self.shadow, 1.0 - self.decay, self.decay, out=self.shadow)
+
+    def apply_shadow(self):
+        for name, p in self.model.named_parameters():
+            self.backup[name] = p.data
+            p.data = self._views[name]
+
+    def restore(self):
+        for name, p in self.model.named_parameters():
+            p.data = self.backup[name]
+        self.backup = {}
+
+
+# ------------------------------------------------------------------------------------------------
+class CyclicCosineDecayLR:
+    """scheduler.py:7-119 restated in closed form (the reference class does not construct on torch >= 2.7:
+    `verbose=` kwarg, scheduler.py:80).  Stepped once per epoch (train2_seq.py:613-615)."""
+
+    def __init__(self, optimizer, init_decay_epochs=15, min_decay_lr=2.5e-6, restart_interval=10, restart_lr=12.5e-5,
+                 warmup_epochs=10, warmup_start_lr=2.5e-6, last_epoch=-1):
+        self.optimizer = optimizer
+        self.base_lrs = [g["lr"] for g in optimizer.param_groups]
+        self.a = (init_decay_epochs, min_decay_lr, restart_interval, restart_lr, warmup_epochs, warmup_start_lr)
+        self.last_epoch = last_epoch
+        self.step()
+
+    @staticmethod
+    def _calc(t, T, lr, min_lr):
+        return min_lr + (lr - min_lr) * ((1 + math.cos(math.pi * t / T)) / 2)
+
+    def lr_at(self, epoch, base_lr):
+        init_decay, min_lr, interval, restart_lr, warm, warm_lr = self.a
+        if warm > 0 and epoch < warm:
+            return self._calc(epoch, warm, warm_lr, base_lr)
+        if epoch < init_decay + warm:
+            return self._calc(epoch - warm, init_decay, base_lr, min_lr)
+        if interval is None:
+            return min_lr
+        return self._calc((epoch - init_decay - warm) % interval, interval,
+                          base_lr if restart_lr is None else restart_lr, min_lr)
+
+    def step(self):
+        self.last_epoch += 1
+        for g, base in zip(self.optimizer.param_groups, self.base_lrs):
+            g["lr"] = self.lr_at(self.last_epoch, base)
+
+    def get_last_lr(self):
+        return [g["lr"] for g in self.optimizer.param_groups]
+
+
+# ------------------------------------------------------------------------------------------------
+def compute_acc(y_pred, y_true, top_k=(1, 2, 3)):
+    """train2_seq.py:347-360: top-k hit rate (percent, 4 decimals) of argsorted beams."""
+    y_pred, y_true = np.asarray(y_pred), np.asarray(y_true)
+    if len(y_pred) != len(y_true):
+        raise Exception("Number of predicted beams does not match number of labels.")
+    hits = [(y_pred[:, :k] == y_true[:, None]).any(axis=1).sum() for k in top_k]
+    return np.round(np.asarray(hits, dtype=np.float64) / len(y_true) * 100, 4)
+
+
+def compute_DBA_score(y_pred, y_true, max_k=3, delta=5):
+    """train2_seq.py:363-383: mean over k<=max_k of 1 - mean_i min_{j<=k} min(|pred_ij - y_i|/delta, 1)."""
+    y_pred, y_true = np.asarray(y_pred), np.asarray(y_true)
+    d = np.minimum(np.abs(y_pred[:, :max_k] - y_true[:, None]) / delta, 1.0)
+    yk = [1 - np.minimum.accumulate(d, axis=1)[:, k].mean() for k in range(max_k)]
+    return float(np.mean(yk))
+
+
+def train_iteration(model, optimizer, batch, ema=None, reducer=None):
+    """One iteration in the order of Engine.train (train2_seq.py:106-134) on the fused harness path.
+    batch = (fronts, lidars, radars, gps, soft_target).  Returns (loss [1], logits)."""
+    optimizer.zero_grad(set_to_none=True)
+    fronts, lidars, radars, gps, target = batch
+    if reducer is not None:
+        reducer.begin()
+    loss, logits = model.train_step_loss(fronts, lidars, radars, gps, target)
+    if reducer is not None:
+        reducer.finish()
+    optimizer.step()
+    if ema is not None:
+        ema.update()
+    return loss, logits

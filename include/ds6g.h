@@ -1,0 +1,134 @@
+/* libds6g.so - C ABI of the MI355X (gfx950) kernel library for the DeepSense6G fusion hot path.
+ *
+ * The reference (szy4017/DeepSense6G_TII) has no FFI: its boundary is the Python class
+ * model2_seq.TransFuser (model2_seq.py:850-894).  deepsense6g_tii_amd/model.py mirrors that class
+ * and binds these entry points with ctypes; every function below states the reference op
+ * (file:line under /root/reference) whose arithmetic it replaces.
+ *
+ * Conventions: all pointers are DEVICE pointers (fp32 unless noted); activations are NHWC,
+ * conv weights OHWI (= torch channels_last storage of an OIHW parameter), Linear weights [N][K]
+ * (torch layout); `stream` is a hipStream_t; every call is asynchronous on that stream, performs
+ * no allocation and no synchronisation (hipGraph-capturable).  Return 0 on success, non-zero on
+ * bad arguments / launch failure (message on stderr).  `ws` arguments are caller-owned scratch.
+ * Dropout masks are a pure function of (seed, seed_off + element index): backward regenerates
+ * them, nothing is stored.
+ */
+#ifndef DS6G_H
+#define DS6G_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int ds6g_version(void);
+/* which implicit-GEMM instantiation the last conv/linear call launched: mode*10 + tile
+ * (mode 0 fwd, 1 dgrad, 2 wgrad; tile 0 128x128, 1 128x64, 2 64x64).  Bench instrumentation only. */
+int ds6g_last_igemm_variant(void);
+
+/* ---- igemm.hip : Conv2d / Linear as implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------
+ * Conv2d(bias=False) of the ResNet trunks: model2_seq.py:495,500,505 (7x7/2 stems), :510-512,
+ * 528-530,546-548,565-567 (BasicBlock 3x3 and 1x1/2 downsample).  C and K multiples of 4. */
+int ds6g_conv2d_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int K, int R, int S,
+                    int stride, int pad, void* stream);
+int ds6g_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int S,
+                      int stride, int pad, int accumulate, void* stream);
+int ds6g_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
+                      int stride, int pad, int accumulate, float* ws, size_t ws_bytes, void* stream);
+/* nn.Linear of the GPT blocks with fused epilogue y = residual + dropout(act(x w^T + b)):
+ * model2_seq.py:97-99 (q,k,v), :109 (proj + resid_drop), :121-126 (MLP, ReLU), :131-132 (residuals). */
+int ds6g_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int relu,
+                    const float* residual, float drop_p, uint64_t seed, uint64_t seed_off, void* stream);
+int ds6g_linear_dgrad(const float* dy, const float* w, float* dx, int M, int N, int K, const float* relu_mask_src,
+                      int accumulate, void* stream);
+int ds6g_linear_wgrad(const float* x, const float* dy, float* dw, int M, int N, int K, int accumulate, float* ws,
+                      size_t ws_bytes, void* stream);
+
+/* ---- norm.hip ----------------------------------------------------------------------------------
+ * BatchNorm2d in train mode (+ReLU, +residual add of BasicBlock): torchvision BasicBlock via
+ * model2_seq.py:496-497,501-502,506-507 and the layer calls above; eval mode uses running stats. */
+size_t ds6g_bn_workspace_bytes(long M, int C);
+int ds6g_bn_stats(const float* x, long M, int C, float eps, float momentum, float* mean, float* invstd,
+                  float* running_mean, float* running_var, void* ws, size_t ws_bytes, void* stream);
+int ds6g_bn_eval_prepare(const float* running_mean, const float* running_var, int C, float eps, float* mean,
+                         float* invstd, void* stream);
+int ds6g_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                  const float* residual, float* y, long M, int C, int relu, void* stream);
+int ds6g_bn_bwd(const float* dy, const float* y_mask, const float* x, const float* mean, const float* invstd,
+                const float* gamma, float* dx, float* dgamma, float* dbeta, float* dres, long M, int C,
+                int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream);
+/* nn.LayerNorm(C), eps 1e-5: model2_seq.py:118-119,131-132,199,274.  C in {64,128,256,512}. */
+int ds6g_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                       int M, int C, float eps, void* stream);
+size_t ds6g_layernorm_bwd_workspace_bytes(int M, int C);
+int ds6g_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* add, float* dx, float* dgamma, float* dbeta, int M, int C,
+                       int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream);
+/* bias gradients: out[c] (+)= sum_r x[r][c] */
+size_t ds6g_colsum_workspace_bytes(long M, int C);
+int ds6g_colsum(const float* x, long M, int C, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- attention.hip : SelfAttention core, model2_seq.py:101-106 (softmax(q k^T/sqrt(hd)), attn_drop,
+ * att @ v, head merge).  q/k/v/o: [B*T][ld], head h at columns h*hd.  hd in {16,32,64,128}. */
+int ds6g_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int T, int nh,
+                       int hd, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* stream);
+int ds6g_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                       const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int T, int nh, int hd,
+                       int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* stream);
+
+/* ---- spatial.hip -------------------------------------------------------------------------------*/
+/* normalize_imagenet + stack + NCHW->NHWC: model2_seq.py:36-45,481-482,491-493 */
+int ds6g_pack_input(const float* src, float* dst, int B, int Cs, int H, int W, int Cd, int frames_per_sample, int t,
+                    int normalize_imagenet, void* stream);
+int ds6g_pad_channels(const float* src, float* dst, long rows, int cin, int cout, int unpad, int accumulate,
+                      void* stream);
+/* MaxPool2d(3,2,1) of the stems: model2_seq.py:498,503,508 */
+int ds6g_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream);
+int ds6g_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, void* stream);
+/* AdaptiveAvgPool2d((8,8)) + token pack + pos_emb + embd dropout: model2_seq.py:414,515-517,261-272 */
+int ds6g_avgpool_tokens_fwd(const float* feat, const float* pos_emb, float* tokens, int N, int H, int C,
+                            int frames_per_sample, int mod_off, int T, float drop_p, uint64_t seed,
+                            uint64_t seed_off, void* stream);
+int ds6g_gps_tokens_fwd(const float* emb, const float* pos_emb, float* tokens, int B, int C, int T, float drop_p,
+                        uint64_t seed, uint64_t seed_off, void* stream);
+int ds6g_dropout(const float* src, float* dst, long n, float drop_p, uint64_t seed, uint64_t seed_off, void* stream);
+int ds6g_avgpool_tokens_bwd(const float* dtok, const float* dfeat_in, float* dfeat, int N, int H, int C,
+                            int frames_per_sample, int mod_off, int T, void* stream);
+/* token unpack + F.interpolate(bilinear, align_corners=False) + residual: model2_seq.py:275-287,521-526,
+ * 539-544,558-563,577-579 */
+int ds6g_upsample_add_fwd(const float* feat, const float* tokens, float* out, int N, int H, int C,
+                          int frames_per_sample, int mod_off, int T, void* stream);
+int ds6g_upsample_add_bwd(const float* dout, float* dtok, int N, int H, int C, int frames_per_sample, int mod_off,
+                          int T, void* stream);
+/* features.avgpool + flatten + cat + sum(dim=1): model2_seq.py:581-595 */
+int ds6g_global_pool(const float* feat, float* pooled, int N, int C, void* stream);
+int ds6g_head_sum(const float* pooled_img, const float* pooled_lidar, const float* pooled_radar, const float* tokens,
+                  float* fused, int B, int C, int fps_img, int fps_other, int T, void* stream);
+int ds6g_head_bwd(const float* dfused, float* dfeat, int N, int C, int frames_per_sample, void* stream);
+int ds6g_feat_to_tokens(const float* dfeat, float* dtok, int N, int C, int frames_per_sample, int mod_off, int T,
+                        void* stream);
+int ds6g_gps_rows(const float* src, float* dst, int B, int C, int T, int to_tokens, int accumulate, int src_bcast,
+                  void* stream);
+int ds6g_axpby(const float* a, const float* b, float* out, long n, float alpha, float beta, void* stream);
+int ds6g_batch_sum(const float* src, float* out, long n, int count, long stride, int accumulate, void* stream);
+
+/* ---- step.hip ----------------------------------------------------------------------------------*/
+/* FocalLoss -> torchvision.ops.sigmoid_focal_loss(alpha .25, gamma 2, mean): train2_seq.py:291-301 */
+int ds6g_focal_loss(const float* logits, const float* target, float* loss, float* dlogits, int n, float alpha,
+                    float gamma, float upstream, void* stream);
+/* optim.AdamW step (train2_seq.py:131,539) fused with EMA.update (train2_seq.py:315-320) */
+int ds6g_adamw_step(float* p, const float* g, float* m, float* v, float* shadow, long n, int step, float lr,
+                    float beta1, float beta2, float eps, float wd, float ema_decay, float grad_scale, void* stream);
+/* vel_emb1..4 and the join MLP: model2_seq.py:422-425,518,536,555,574,863-869 */
+int ds6g_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K,
+                          int rows_per_group, long group_stride, int relu, void* stream);
+int ds6g_small_linear_bwd(const float* dy, const float* y_mask, const float* x, const float* w, float* dx, float* dw,
+                          float* db, int M, int N, int K, int rows_per_group, long group_stride,
+                          int dx_rows_per_group, long dx_group_stride, int accumulate_dx, int accumulate_params,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DS6G_H */

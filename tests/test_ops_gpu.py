@@ -1,0 +1,455 @@
+"""Op-level parity: every HIP kernel of libds6g.so (called through the C ABI) against a plain
+PyTorch fp32 CPU reference of the same op on the same seeded inputs.  Tolerances are fp32
+summation-order tolerances, written per test."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from deepsense6g_tii_amd import ops
+    return ops
+
+
+def nhwc(t):  # NCHW cpu -> NHWC gpu
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):  # NHWC gpu -> NCHW cpu
+    return t.cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def ohwi(w):
+    return w.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def close(a, b, rtol=1e-4, atol=1e-4):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= atol + rtol * ref, f"max err {err:.3e} vs ref max {ref:.3e}"
+
+
+CONV_CASES = [
+    # N, H, W, C, K, R, stride, pad
+    (2, 16, 16, 64, 64, 3, 1, 1),
+    (3, 16, 16, 64, 128, 3, 2, 1),
+    (2, 16, 16, 64, 128, 1, 2, 0),
+    (2, 32, 32, 4, 64, 7, 2, 3),
+    (5, 8, 8, 256, 512, 3, 2, 1),
+    (1, 12, 20, 128, 192, 3, 1, 1),   # ragged: M, N not multiples of the tiles
+    (10, 64, 64, 64, 64, 3, 1, 1),    # takes the 128x64 tile path
+    (4, 32, 32, 128, 128, 3, 1, 1),   # takes the 128x128 tile path
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(dev, case):
+    ops = _ops()
+    N, H, W, C, K, R, st, pad = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) / math.sqrt(C * R * R)
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    y = F.conv2d(x, w, None, st, pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+
+    ws = ops.Workspace(dev, 64 << 20)
+    xg, wg, dyg = nhwc(x.detach()), ohwi(w.detach()), nhwc(dy)
+    yg = ops.conv2d_fwd(xg, wg.data_ptr(), K, R, R, st, pad)
+    close(nchw(yg), y.detach(), 2e-5, 2e-5)
+    dxg = ops.conv2d_dgrad(dyg, wg.data_ptr(), tuple(xg.shape), R, R, st, pad)
+    close(nchw(dxg), x.grad, 2e-5, 2e-5)
+    # accumulate path
+    base = torch.randn(xg.shape, generator=g).cuda()
+    acc = base.clone()
+    ops.conv2d_dgrad(dyg, wg.data_ptr(), tuple(xg.shape), R, R, st, pad, out=acc, accumulate=True)
+    close(nchw(acc - base), x.grad, 2e-5, 2e-5)
+    dwg = torch.empty_like(wg)
+    ops.conv2d_wgrad(xg, dyg, dwg.data_ptr(), R, R, st, pad, ws)
+    close(dwg.cpu().permute(0, 3, 1, 2), w.grad, 1e-4, 1e-4)
+    torch.cuda.synchronize()
+
+
+LIN_CASES = [(962 * 2, 64, 64), (962 * 2, 256, 64), (1000, 512, 2048), (777, 2048, 512), (37, 64, 128)]
+
+
+@pytest.mark.parametrize("M,N,K", LIN_CASES)
+def test_linear(dev, M, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g, requires_grad=True)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).requires_grad_(True)
+    b = torch.randn(N, generator=g, requires_grad=True)
+    res = torch.randn(M, N, generator=g)
+    ws = ops.Workspace(dev, 64 << 20)
+    xg, wg, bg, rg = x.detach().cuda(), w.detach().cuda(), b.detach().cuda(), res.cuda()
+
+    y = F.linear(x, w, b)
+    close(ops.linear_fwd(xg, wg.data_ptr(), bg.data_ptr(), N), y.detach(), 2e-5, 2e-5)
+    close(ops.linear_fwd(xg, wg.data_ptr(), bg.data_ptr(), N, relu=True), F.relu(y).detach(), 2e-5, 2e-5)
+    close(ops.linear_fwd(xg, wg.data_ptr(), bg.data_ptr(), N, residual=rg), (y + res).detach(), 2e-5, 2e-5)
+    close(ops.linear_fwd(xg, wg.data_ptr(), 0, N), F.linear(x, w).detach(), 2e-5, 2e-5)
+
+    h = F.relu(y)
+    dy = torch.randn(M, N, generator=g)
+    h.backward(dy)
+    dyg = dy.cuda()
+    hg = h.detach().cuda()
+    # relu mask fused into the *previous* layer's dgrad: here emulate dgrad of this layer w/o mask
+    dmask = dy * (h.detach() > 0)
+    dxg = ops.linear_dgrad(dmask.cuda(), wg.data_ptr(), K)
+    close(dxg, x.grad, 2e-5, 2e-5)
+    # mask_src path: dx * (mask_src > 0)
+    msk = torch.randn(M, K, generator=g)
+    dxm = ops.linear_dgrad(dmask.cuda(), wg.data_ptr(), K, relu_mask_src=msk.cuda())
+    close(dxm, x.grad * (msk > 0), 2e-5, 2e-5)
+    dwg = torch.empty_like(wg)
+    ops.linear_wgrad(xg, dmask.cuda(), dwg.data_ptr(), ws)
+    close(dwg, w.grad, 1e-4, 1e-4)
+    dbg = torch.empty_like(bg)
+    ops.colsum(dmask.cuda(), dbg.data_ptr(), ws)
+    close(dbg, b.grad, 1e-4, 1e-4)
+    ops.colsum(dmask.cuda(), dbg.data_ptr(), ws, accumulate=True)
+    close(dbg, 2 * b.grad, 1e-4, 1e-4)
+    del hg, dyg
+    torch.cuda.synchronize()
+
+
+def test_linear_dropout_epilogue(dev):
+    ops = _ops()
+    M, N, K = 2048, 256, 64
+    x = torch.randn(M, K).cuda()
+    w = torch.randn(N, K).cuda() / 8
+    res = torch.randn(M, N).cuda()
+    y0 = ops.linear_fwd(x, w.data_ptr(), 0, N)
+    y = ops.linear_fwd(x, w.data_ptr(), 0, N, residual=res, drop_p=0.1, seed=1234, seed_off=77)
+    z = y - res
+    kept = (z != 0)
+    frac = 1.0 - kept.float().mean().item()
+    assert abs(frac - 0.1) < 0.005, frac
+    close(z[kept], (y0 / 0.9)[kept], 1e-5, 1e-5)
+    # the standalone dropout kernel regenerates the identical mask
+    d = ops.dropout(y0, 0.1, 1234, 77)
+    close(d, z, 1e-6, 1e-6)
+    # different offset -> different mask
+    d2 = ops.dropout(y0, 0.1, 1234, 78)
+    assert ((d2 != 0) != kept).float().mean().item() > 0.05
+
+
+@pytest.mark.parametrize("M,C", [(60 * 16 * 16, 64), (10 * 8 * 8, 512), (3 * 5 * 7, 128), (5000, 256)])
+def test_batchnorm(dev, M, C):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * 2 + 3).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    res = torch.randn(M, C, generator=g).requires_grad_(True)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    # torch reference on (M, C, 1, 1)... use (1, C, M, 1) so that statistics run over M
+    xr = x.t().reshape(1, C, M, 1)
+    y = F.batch_norm(xr, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    out = F.relu(y + res.t().reshape(1, C, M, 1))
+    dout = torch.randn(out.shape, generator=g)
+    out.backward(dout)
+
+    ws = ops.Workspace(dev, 64 << 20)
+    xg = x.detach().cuda()
+    mean = torch.empty(C, device=dev)
+    invstd = torch.empty(C, device=dev)
+    rmg, rvg = rm0.cuda(), rv0.cuda()
+    ops.bn_stats(M, C, xg, mean, invstd, rmg.data_ptr(), rvg.data_ptr(), ws)
+    close(rmg, rm, 1e-5, 1e-5)
+    close(rvg, rv, 1e-5, 1e-5)
+    gg, bg = gamma.detach().cuda(), beta.detach().cuda()
+    og = ops.bn_apply(xg, mean, invstd, gg.data_ptr(), bg.data_ptr(), True, residual=res.detach().cuda())
+    close(og, out.detach().reshape(C, M).t(), 1e-5, 1e-5)
+    dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    # the ReLU mask comes from the CPU output so that a value within rounding of zero cannot flip it
+    mask_src = out.detach().reshape(C, M).t().contiguous().cuda()
+    dx, dres = ops.bn_bwd(dout.reshape(C, M).t().contiguous().cuda(), mask_src, xg, mean, invstd, gg.data_ptr(),
+                          dgam.data_ptr(), dbet.data_ptr(), ws, want_dres=True)
+    close(dx, x.grad, 1e-4, 1e-5)
+    close(dres, res.grad, 1e-5, 1e-6)
+    close(dgam, gamma.grad, 1e-4, 1e-4)
+    close(dbet, beta.grad, 1e-4, 1e-4)
+    # eval-mode prepare
+    ops.bn_eval_prepare(rmg.data_ptr(), rvg.data_ptr(), C, mean, invstd)
+    ye = ops.bn_apply(xg, mean, invstd, gg.data_ptr(), bg.data_ptr(), False)
+    ref = F.batch_norm(xr.detach(), rm, rv, gamma.detach(), beta.detach(), False, 0.1, 1e-5)
+    close(ye, ref.reshape(C, M).t(), 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("M,C", [(962 * 2, 64), (962, 128), (500, 256), (333, 512)])
+def test_layernorm(dev, M, C):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    y = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    dy = torch.randn(M, C, generator=g)
+    y.backward(dy)
+    ws = ops.Workspace(dev, 64 << 20)
+    xg, gg, bg = x.detach().cuda(), gamma.detach().cuda(), beta.detach().cuda()
+    yg, mean, rstd = ops.layernorm_fwd(xg, gg.data_ptr(), bg.data_ptr())
+    close(yg, y.detach(), 1e-5, 1e-5)
+    add = torch.randn(M, C, generator=g)
+    dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    dx = ops.layernorm_bwd(dy.cuda(), xg, mean, rstd, gg.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), ws,
+                           add=add.cuda())
+    close(dx, x.grad + add, 1e-5, 1e-5)
+    close(dgam, gamma.grad, 1e-4, 1e-4)
+    close(dbet, beta.grad, 1e-4, 1e-4)
+
+
+def _attn_ref(q, k, v, B, T, nh):
+    C = q.shape[1]
+    hd = C // nh
+
+    def heads(t):
+        return t.view(B, T, nh, hd).transpose(1, 2)
+
+    att = (heads(q) @ heads(k).transpose(-2, -1)) * (1.0 / math.sqrt(hd))
+    att = torch.softmax(att, dim=-1)
+    return (att @ heads(v)).transpose(1, 2).reshape(B * T, C), att
+
+
+@pytest.mark.parametrize("B,T,nh,hd", [(2, 962, 4, 16), (2, 962, 4, 32), (1, 962, 4, 64), (1, 962, 4, 128),
+                                       (3, 194, 4, 16), (12, 130, 4, 32), (1, 33, 2, 64), (16, 962, 4, 16)])
+def test_attention(dev, B, T, nh, hd):
+    ops = _ops()
+    C = nh * hd
+    g = torch.Generator().manual_seed(T + hd)
+    q = torch.randn(B * T, C, generator=g, requires_grad=True)
+    k = torch.randn(B * T, C, generator=g, requires_grad=True)
+    v = torch.randn(B * T, C, generator=g, requires_grad=True)
+    with torch.no_grad():
+        q[5] *= 6.0  # a spiky row: exercises the online-softmax rescale
+    o, att = _attn_ref(q, k, v, B, T, nh)
+    do = torch.randn(B * T, C, generator=g)
+    o.backward(do)
+    qg, kg, vg = q.detach().cuda(), k.detach().cuda(), v.detach().cuda()
+    og, lse = ops.attention_fwd(qg, kg, vg, B, T, nh)
+    close(og, o.detach(), 2e-5, 2e-5)
+    dq, dk, dv = ops.attention_bwd(qg, kg, vg, og, do.cuda(), lse, B, T, nh)
+    close(dq, q.grad, 1e-4, 2e-5)
+    close(dk, k.grad, 1e-4, 2e-5)
+    close(dv, v.grad, 1e-4, 2e-5)
+
+
+def test_attention_dropout(dev):
+    """With dropout the forward must equal (P * mask / (1-p)) V for SOME Bernoulli(1-p) mask, and the
+    backward must use the same mask.  The mask is recovered from the kernel itself with V = identity."""
+    ops = _ops()
+    B, T, nh, hd = 1, 64, 1, 64
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(T, hd, generator=g)
+    k = torch.randn(T, hd, generator=g)
+    eye = torch.eye(T)  # V = I -> O = dropped probabilities
+    p = 0.25
+    og, lse = ops.attention_fwd(q.cuda(), k.cuda(), eye.cuda(), B, T, nh, drop_p=p, seed=99, seed_off=1000)
+    att = torch.softmax((q @ k.t()) / math.sqrt(hd), dim=-1)
+    pd = og.cpu()
+    mask = (pd != 0).float()
+    frac = 1 - mask.mean().item()
+    assert abs(frac - p) < 0.03, frac
+    close(pd, att * mask / (1 - p), 2e-5, 1e-6)
+    # backward against autograd with that fixed mask
+    v = torch.randn(T, hd, generator=g)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    o = ((torch.softmax((qr @ kr.t()) / math.sqrt(hd), dim=-1) * mask / (1 - p)) @ vr)
+    do = torch.randn(T, hd, generator=g)
+    o.backward(do)
+    og2, lse2 = ops.attention_fwd(q.cuda(), k.cuda(), v.cuda(), B, T, nh, drop_p=p, seed=99, seed_off=1000)
+    close(og2, o.detach(), 2e-5, 2e-5)
+    dq, dk, dv = ops.attention_bwd(q.cuda(), k.cuda(), v.cuda(), og2, do.cuda(), lse2, B, T, nh, drop_p=p, seed=99,
+                                   seed_off=1000)
+    close(dq, qr.grad, 1e-4, 2e-5)
+    close(dk, kr.grad, 1e-4, 2e-5)
+    close(dv, vr.grad, 1e-4, 2e-5)
+
+
+def test_maxpool(dev):
+    from deepsense6g_tii_amd._lib import lib
+    N, H, W, C = 3, 32, 32, 64
+    g = torch.Generator().manual_seed(3)
+    x = F.relu(torch.randn(N, C, H, W, generator=g)).requires_grad_(True)  # many exact-zero ties
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xg = nhwc(x.detach())
+    yg = torch.empty(N, 16, 16, C, device=dev)
+    idx = torch.empty(N, 16, 16, C, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    lib().maxpool3x3s2_fwd(xg.data_ptr(), yg.data_ptr(), idx.data_ptr(), N, H, W, C, st)
+    close(nchw(yg), y.detach(), 0, 0)
+    dxg = torch.empty_like(xg)
+    dyg = nhwc(dy)
+    lib().maxpool3x3s2_bwd(dyg.data_ptr(), idx.data_ptr(), dxg.data_ptr(), N, H, W, C, st)
+    # gradient routed to a zero of the ReLU output is killed by the ReLU backward: compare masked
+    m = (x.detach() > 0).float()
+    close(nchw(dxg) * m, x.grad * m, 1e-6, 1e-6)
+    # total mass is conserved regardless of tie-breaking
+    close(nchw(dxg).sum(dim=(2, 3)), x.grad.sum(dim=(2, 3)), 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("H,C", [(64, 64), (32, 128), (16, 256), (8, 512)])
+def test_token_pool_and_upsample(dev, H, C):
+    """avgpool->token rows (+pos_emb) and bilinear upsample-add (+adjoint) against torch."""
+    from deepsense6g_tii_amd._lib import lib
+    B, S = 2, 5
+    N = B * S
+    T = 3 * S * 64 + 2
+    g = torch.Generator().manual_seed(H)
+    st = torch.cuda.current_stream().cuda_stream
+    feats = [torch.randn(N, C, H, H, generator=g, requires_grad=True) for _ in range(3)]
+    pos = torch.randn(1, T, C, generator=g)
+    gps = torch.randn(B, 2, C, generator=g)
+    emb = [F.adaptive_avg_pool2d(f, (8, 8)) for f in feats]
+    tok = torch.cat([e.view(B, S, C, 64).permute(0, 1, 3, 2).reshape(B, S * 64, C) for e in emb] + [gps], dim=1) + pos
+    tokens = torch.empty(B, T, C, device=dev)
+    posg = pos.cuda()
+    featg = [nhwc(f.detach()) for f in feats]  # keep device tensors alive while kernels use their pointers
+    gpsg = gps.cuda()
+    for m, f in enumerate(featg):
+        lib().avgpool_tokens_fwd(f.data_ptr(), posg.data_ptr(), tokens.data_ptr(), N, H, C, S,
+                                 m * S * 64, T, 0.0, 0, 0, st)
+    lib().gps_tokens_fwd(gpsg.data_ptr(), posg.data_ptr(), tokens.data_ptr(), B, C, T, 0.0, 0, 0, st)
+    close(tokens, tok.detach(), 1e-5, 1e-5)
+
+    # upsample-add: out = feat + up(tokmap)
+    xo = torch.randn(B, T, C, generator=g, requires_grad=True)
+    sp = xo[:, :T - 2].view(B, 3 * S, 8, 8, C).permute(0, 1, 4, 2, 3)
+    outs, ref_outs = [], []
+    xog = xo.detach().cuda()
+    for m, f in enumerate(feats):
+        tm = sp[:, m * S:(m + 1) * S].reshape(N, C, 8, 8)
+        up = F.interpolate(tm, scale_factor=H // 8, mode="bilinear") if H > 8 else tm
+        ref_outs.append(f + up)
+        og = torch.empty(N, H, H, C, device=dev)
+        lib().upsample_add_fwd(featg[m].data_ptr(), xog.data_ptr(), og.data_ptr(), N, H, C, S, m * S * 64, T, st)
+        outs.append(og)
+        close(nchw(og), ref_outs[-1].detach(), 1e-5, 1e-5)
+    douts = [torch.randn(N, C, H, H, generator=g) for _ in range(3)]
+    sum((r * d).sum() for r, d in zip(ref_outs, douts)).backward()
+    dtok = torch.zeros(B, T, C, device=dev)
+    doutg = [nhwc(d) for d in douts]
+    for m, d in enumerate(doutg):
+        lib().upsample_add_bwd(d.data_ptr(), dtok.data_ptr(), N, H, C, S, m * S * 64, T, st)
+    close(dtok[:, :T - 2], xo.grad[:, :T - 2], 1e-4, 1e-5)
+
+    # avgpool backward (+ pass-through gradient)
+    dtk = torch.randn(B, T, C, generator=g)
+    for f in feats:
+        f.grad = None
+    (tok * dtk).sum().backward()
+    dtkg = dtk.cuda()
+    for m, f in enumerate(feats):
+        dfe = torch.empty(N, H, H, C, device=dev)
+        extra = torch.randn(N, H, H, C, generator=g)
+        extrag = extra.cuda()
+        lib().avgpool_tokens_bwd(dtkg.data_ptr(), extrag.data_ptr(), dfe.data_ptr(), N, H, C, S,
+                                 m * S * 64, T, st)
+        close(nchw(dfe), f.grad + extra.permute(0, 3, 1, 2), 1e-5, 1e-5)
+
+
+def test_focal_adamw_small_linear(dev):
+    from deepsense6g_tii_amd._lib import lib
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(0)
+    # focal loss (soft targets) fwd + grad
+    x = (torch.randn(12, 64, generator=g) * 2).requires_grad_(True)
+    t = torch.rand(12, 64, generator=g) * (torch.rand(12, 64, generator=g) < 0.2)
+    p = torch.sigmoid(x)
+    ce = F.binary_cross_entropy_with_logits(x, t, reduction="none")
+    pt = p * t + (1 - p) * (1 - t)
+    loss = ((0.25 * t + 0.75 * (1 - t)) * ce * (1 - pt) ** 2).mean()
+    loss.backward()
+    lg = torch.empty(1, device=dev)
+    dxg = torch.empty(12, 64, device=dev)
+    xg, tg = x.detach().cuda(), t.cuda()
+    lib().focal_loss(xg.data_ptr(), tg.data_ptr(), lg.data_ptr(), dxg.data_ptr(), 768, 0.25, 2.0, 1.0, st)
+    close(lg, loss.detach().reshape(1), 1e-5, 1e-7)
+    close(dxg, x.grad, 1e-4, 1e-8)
+
+    # AdamW + EMA, three steps against torch.optim.AdamW
+    n = 4096 + 8
+    prm = torch.randn(n, generator=g)
+    ref = prm.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=1e-3)
+    pg, m, v = prm.cuda(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    shadow = pg.clone()
+    sh_ref = prm.clone()
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g)
+        ref.grad = grad.clone()
+        opt.step()
+        sh_ref = 0.001 * ref.detach() + 0.999 * sh_ref
+        gradg = grad.cuda()
+        lib().adamw_step(pg.data_ptr(), gradg.data_ptr(), m.data_ptr(), v.data_ptr(), shadow.data_ptr(), n, step,
+                         1e-3, 0.9, 0.999, 1e-8, 0.01, 0.999, 1.0, st)
+    close(pg, ref.detach(), 1e-6, 1e-6)
+    close(shadow, sh_ref, 1e-6, 1e-6)
+
+    # small linear with grouped row addressing (GPS rows of a token buffer)
+    B, T, K, N = 3, 10, 64, 128
+    buf = torch.randn(B, T, K, generator=g, requires_grad=True)
+    w = (torch.randn(N, K, generator=g) / 8).requires_grad_(True)
+    b = torch.randn(N, generator=g, requires_grad=True)
+    y = F.relu(F.linear(buf[:, T - 2:], w, b))
+    dy = torch.randn(B, 2, N, generator=g)
+    y.backward(dy)
+    bufg, wg, bg = buf.detach().cuda(), w.detach().cuda(), b.detach().cuda()
+    yg = torch.empty(B, 2, N, device=dev)
+    xptr = bufg.data_ptr() + (T - 2) * K * 4
+    lib().small_linear_fwd(xptr, wg.data_ptr(), bg.data_ptr(), yg.data_ptr(), 2 * B, N, K, 2, T * K, 1, st)
+    close(yg, y.detach(), 1e-5, 1e-5)
+    dbuf = torch.zeros(B, T, K, device=dev)
+    dwg, dbg = torch.empty_like(wg), torch.empty_like(bg)
+    dyg = dy.cuda()
+    lib().small_linear_bwd(dyg.data_ptr(), yg.data_ptr(), xptr, wg.data_ptr(), dbuf.data_ptr() + (T - 2) * K * 4,
+                           dwg.data_ptr(), dbg.data_ptr(), 2 * B, N, K, 2, T * K, 2, T * K, 1, 0, st)
+    close(dbuf, buf.grad, 1e-5, 1e-5)
+    close(dwg, w.grad, 1e-5, 1e-5)
+    close(dbg, b.grad, 1e-5, 1e-5)
+
+
+def test_pack_input_and_misc(dev):
+    from deepsense6g_tii_amd._lib import lib
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(1)
+    B, S, H = 2, 5, 16
+    imgs = [torch.randint(0, 256, (B, 3, H, H), generator=g).float() for _ in range(S)]
+    dst = torch.empty(B * S, H, H, 4, device=dev)
+    imgs_g = [im.cuda() for im in imgs]
+    for t, im in enumerate(imgs_g):
+        lib().pack_input(im.data_ptr(), dst.data_ptr(), B, 3, H, H, 4, S, t, 1, st)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    ref = torch.stack([(im / 255.0 - mean) / std for im in imgs], dim=1).view(B * S, 3, H, H)
+    out = nchw(dst)
+    close(out[:, :3], ref, 1e-6, 1e-6)
+    assert out[:, 3].abs().max().item() == 0.0
+    # batch_sum, pad_channels
+    src = torch.randn(6, 1000, generator=g)
+    o = torch.empty(1000, device=dev)
+    srcg = src.cuda()
+    lib().batch_sum(srcg.data_ptr(), o.data_ptr(), 1000, 6, 1000, 0, st)
+    close(o, src.sum(0), 1e-5, 1e-5)
+    w = torch.randn(64 * 49, 3, generator=g)
+    wp = torch.empty(64 * 49, 4, device=dev)
+    wg = w.cuda()
+    lib().pad_channels(wg.data_ptr(), wp.data_ptr(), 64 * 49, 3, 4, 0, 0, st)
+    close(wp[:, :3], w, 0, 0)
+    assert wp[:, 3].abs().max().item() == 0.0
+    back = torch.empty(64 * 49, 3, device=dev)
+    lib().pad_channels(wp.data_ptr(), back.data_ptr(), 64 * 49, 3, 4, 1, 0, st)
+    close(back, w, 0, 0)
