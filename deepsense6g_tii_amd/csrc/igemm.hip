@@ -7,10 +7,15 @@
 // Covers the reference's Conv2d / Linear call sites: model2_seq.py:495-512,528-530,546-548,
 // 565-567 (ResNet trunks), :83-90,:97-99,:109,:121-126 (GPT linears), :422-425,:863-869.
 //
-// Tiling: 256 threads = 4 waves (2x2); block tile BM x BN, BK = 16; operands are staged in LDS
-// k-major ([k][row]) so that a wave's MFMA operand read (lane l -> row l&31, k = l>>5) is a
-// conflict-free ds_read_b32 of 32 consecutive floats; global loads are 16-B per lane and
-// register-prefetched one k-tile ahead (single barrier per k-tile, two LDS buffers).
+// Tiling: 256 threads = 4 waves (2x2); block tile BM x BN, BK = 16.  Operands are staged in LDS
+// row-major [row][BK+4] (80-B rows).  The MFMA k-order inside a tile is permuted - step kk of lane
+// half h consumes tile column 8h+kk for BOTH operands - so a lane's 8 k-values are 32 contiguous
+// bytes: two ds_read_b128 per 32-row fragment, conflict-free at the 20-float row stride, all issued
+// before the 8-step MFMA chain (one exposed LDS latency per k-tile instead of one per k-step).
+// Global loads are 16 B per lane, register-prefetched one k-tile ahead (single barrier per k-tile,
+// two LDS buffers).  Row-contiguous sources (both wgrad operands, dgrad weights) keep a k-major
+// image [k][rows+4] instead: their loads stay fully coalesced (whole 256/512-B rows per wave),
+// stores are ds_write_b128 and a fragment is 8 conflict-free ds_read_b32, again issued up front.
 #include "common.h"
 
 namespace {
@@ -37,163 +42,197 @@ struct IgemmParams {
     int k_per_split;     // multiple of 16
     size_t split_stride; // elements between split-K slabs
     int tiles_n;
+    int dbg;  // ablation flags (timing experiments only): 1 skip in-loop global loads, 2 skip LDS stores, 4 skip barrier
 };
 
 constexpr int BK = 16;
 
 template <int MODE, int BM, int BN>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
-    constexpr int LDA = BM + 4;
-    constexpr int LDB = BN + 4;
+    constexpr int LDK = BK + 4;  // 20 floats: 16-B aligned rows, conflict-free b128 fragment reads
     constexpr int TM = BM / 64;  // 32x32 MFMA tiles per wave along M (wave grid 2x2)
     constexpr int TN = BN / 64;
     constexpr int A_LD = BM * 4 / 256;  // float4 loads per thread per k-tile
     constexpr int B_LD = BN * 4 / 256;
-    __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+    constexpr bool A_KMAJOR = (MODE == MODE_WGRAD);                 // A source contiguous along rows (m)
+    constexpr bool B_KMAJOR = (MODE != MODE_FWD);                   // B source contiguous along rows (n)
+    constexpr int A_FLOATS = A_KMAJOR ? BK * (BM + 4) : BM * LDK;
+    constexpr int B_FLOATS = B_KMAJOR ? BK * (BN + 4) : BN * LDK;
+    __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][B_FLOATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile_m = blockIdx.x / p.tiles_n;
-    const int tile_n = blockIdx.x - tile_m * p.tiles_n;
+    // XCD-aware tile order: hardware deals consecutive workgroups round-robin over the 8 XCDs (each
+    // with a private L2); remap so that every XCD walks a contiguous run of tiles (tile_n fastest),
+    // i.e. tiles sharing A rows / neighbouring image rows hit the same L2.  Bijective for any grid.
+    int wg;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tile_m = wg / p.tiles_n;
+    const int tile_n = wg - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int split = blockIdx.z;
     const int kbegin = (MODE == MODE_WGRAD) ? split * p.k_per_split : 0;
     const int kend = (MODE == MODE_WGRAD) ? min(p.Kg, kbegin + p.k_per_split) : p.Kg;
     const int nk = (kend - kbegin + BK - 1) / BK;
 
-    // ---- per-thread, k-independent load coordinates ------------------------------------------
+    // ---- per-thread load state.  All index arithmetic that needs a division happens ONCE here; the k-loop
+    // only advances (channel, tap) / (pixel) counters by BK with compare-and-wrap.
     // A operand
-    int a_n[A_LD], a_y[A_LD], a_x[A_LD];
+    const float* a_base[A_LD];   // FWD/DGRAD: image base of this row; WGRAD: column base
+    int a_y[A_LD], a_x[A_LD];    // FWD: ih0, iw0 ; DGRAD: h+pad, w+pad
+    int a_c[A_LD], a_r[A_LD], a_s[A_LD], a_k[A_LD];  // running channel / tap / global-k of this thread's chunk
     bool a_ok[A_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
         const int idx = tid + i * 256;
-        if (MODE == MODE_FWD) {
+        if (MODE == MODE_FWD || MODE == MODE_DGRAD) {
             const int m = m0 + (idx >> 2);
             a_ok[i] = m < p.Mg;
             const int mm = a_ok[i] ? m : 0;
-            const int ow = mm % p.Wo;
-            const int t = mm / p.Wo;
-            const int oh = t % p.Ho;
-            a_n[i] = t / p.Ho;
-            a_y[i] = oh * p.stride - p.pad;
-            a_x[i] = ow * p.stride - p.pad;
-        } else if (MODE == MODE_DGRAD) {
-            const int m = m0 + (idx >> 2);
-            a_ok[i] = m < p.Mg;
-            const int mm = a_ok[i] ? m : 0;
-            const int w_ = mm % p.W;
-            const int t = mm / p.W;
-            const int h_ = t % p.H;
-            a_n[i] = t / p.H;
-            a_y[i] = h_ + p.pad;
-            a_x[i] = w_ + p.pad;
+            const int cin = (MODE == MODE_FWD) ? p.C : p.K;
+            const int kg = (idx & 3) * 4;
+            a_k[i] = kg;
+            const int tap = kg / cin;
+            a_c[i] = kg - tap * cin;
+            a_r[i] = tap / p.S;
+            a_s[i] = tap - a_r[i] * p.S;
+            if (MODE == MODE_FWD) {
+                const int ow = mm % p.Wo;
+                const int t = mm / p.Wo;
+                const int oh = t % p.Ho;
+                const int n = t / p.Ho;
+                a_y[i] = oh * p.stride - p.pad;
+                a_x[i] = ow * p.stride - p.pad;
+                a_base[i] = p.a_src + (long)n * p.H * p.W * p.C;
+            } else {
+                const int w_ = mm % p.W;
+                const int t = mm / p.W;
+                const int h_ = t % p.H;
+                const int n = t / p.H;
+                a_y[i] = h_ + p.pad;
+                a_x[i] = w_ + p.pad;
+                a_base[i] = p.a_src + (long)n * p.Ho * p.Wo * p.K;
+            }
         } else {
-            const int mc = idx % (BM / 4);
+            const int mc = idx % (BM / 4);  // row-contiguous source: a wave reads whole rows
             a_ok[i] = (m0 + mc * 4) < p.Mg;
-            a_n[i] = 0; a_y[i] = 0; a_x[i] = 0;
+            a_k[i] = kbegin + idx / (BM / 4);  // pixel
+            a_base[i] = p.a_src + m0 + mc * 4;
+            a_y[i] = a_x[i] = a_c[i] = a_r[i] = a_s[i] = 0;
         }
     }
-    // B operand (WGRAD: fixed (r,s,c) per thread)
-    int b_r[B_LD], b_s[B_LD], b_c[B_LD];
+    // B operand
+    const float* b_base[B_LD];
+    int b_r[B_LD], b_s[B_LD];      // WGRAD: fixed tap of this thread's column chunk
+    int b_k[B_LD];                 // running global k (FWD/DGRAD) or pixel (WGRAD)
+    int b_o[B_LD], b_t[B_LD];      // DGRAD: running (out channel, tap); WGRAD: running (ow, oh)
+    int b_n[B_LD];                 // WGRAD: running image index
     bool b_ok[B_LD];
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
         const int idx = tid + i * 256;
-        if (MODE == MODE_WGRAD) {
+        b_r[i] = b_s[i] = b_o[i] = b_t[i] = b_n[i] = 0;
+        if (MODE == MODE_FWD) {
+            b_ok[i] = (n0 + (idx >> 2)) < p.Ng;
+            b_k[i] = (idx & 3) * 4;
+            b_base[i] = p.b_src + (long)(n0 + (idx >> 2)) * p.Kg;
+        } else if (MODE == MODE_DGRAD) {
+            b_ok[i] = (n0 + (idx % (BN / 4)) * 4) < p.Ng;
+            const int kg = idx / (BN / 4);
+            b_k[i] = kg;
+            b_t[i] = kg / p.K;
+            b_o[i] = kg - b_t[i] * p.K;
+            b_base[i] = p.b_src + n0 + (idx % (BN / 4)) * 4;
+        } else {
             const int ncol = n0 + (idx % (BN / 4)) * 4;
             b_ok[i] = ncol < p.Ng;
             const int nn = b_ok[i] ? ncol : 0;
             const int tap = nn / p.C;
-            b_c[i] = nn - tap * p.C;
             b_r[i] = tap / p.S;
             b_s[i] = tap - b_r[i] * p.S;
-        } else if (MODE == MODE_FWD) {
-            b_ok[i] = (n0 + (idx >> 2)) < p.Ng;
-            b_r[i] = b_s[i] = b_c[i] = 0;
-        } else {
-            b_ok[i] = (n0 + (idx % (BN / 4)) * 4) < p.Ng;
-            b_r[i] = b_s[i] = b_c[i] = 0;
+            b_base[i] = p.b_src + (nn - tap * p.C);
+            const int pix = kbegin + idx / (BN / 4);
+            b_k[i] = pix;
+            const int pp = pix < p.Kg ? pix : 0;
+            b_o[i] = pp % p.Wo;           // ow
+            const int t = pp / p.Wo;
+            b_t[i] = t % p.Ho;            // oh
+            b_n[i] = t / p.Ho;
         }
     }
 
     f32x4 a_reg[A_LD], b_reg[B_LD];
 
-    auto load_tiles = [&](int kt) {
-        const int kb = kbegin + kt * BK;
+    // loads the NEXT k-tile (state is advanced by BK afterwards): must be called for kt = 0, 1, 2, ... in order
+    auto load_tiles = [&]() {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            const int idx = tid + i * 256;
-            const float* ptr = nullptr;
-            bool ok = a_ok[i];
+            const float* ptr;
+            bool ok = a_ok[i] && a_k[i] < kend;
             if (MODE == MODE_FWD) {
-                const int kg = kb + (idx & 3) * 4;
-                const int tap = kg / p.C;
-                const int c = kg - tap * p.C;
-                const int r = tap / p.S;
-                const int s = tap - r * p.S;
-                const int ih = a_y[i] + r, iw = a_x[i] + s;
-                ok = ok && kg < kend && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-                ptr = p.a_src + (((long)a_n[i] * p.H + ih) * p.W + iw) * p.C + c;
+                const int ih = a_y[i] + a_r[i], iw = a_x[i] + a_s[i];
+                ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                ptr = a_base[i] + ((long)ih * p.W + iw) * p.C + a_c[i];
             } else if (MODE == MODE_DGRAD) {
-                const int kg = kb + (idx & 3) * 4;
-                const int tap = kg / p.K;
-                const int o = kg - tap * p.K;
-                const int r = tap / p.S;
-                const int s = tap - r * p.S;
-                const int th = a_y[i] - r, tw = a_x[i] - s;
+                const int th = a_y[i] - a_r[i], tw = a_x[i] - a_s[i];
                 int oh = th, ow = tw;
                 bool okk = th >= 0 && tw >= 0;
-                if (p.stride != 1) {
+                if (p.stride == 2) {
+                    oh = th >> 1;
+                    ow = tw >> 1;
+                    okk = okk && !((th | tw) & 1);
+                } else if (p.stride != 1) {
                     oh = th / p.stride;
                     ow = tw / p.stride;
                     okk = okk && (oh * p.stride == th) && (ow * p.stride == tw);
                 }
-                ok = ok && okk && kg < kend && oh < p.Ho && ow < p.Wo;
-                ptr = p.a_src + (((long)a_n[i] * p.Ho + oh) * p.Wo + ow) * p.K + o;
+                ok = ok && okk && oh < p.Ho && ow < p.Wo;
+                ptr = a_base[i] + ((long)oh * p.Wo + ow) * p.K + a_c[i];
             } else {
-                const int krow = idx / (BM / 4);
-                const int mc = idx % (BM / 4);
-                const int pix = kb + krow;
-                ok = ok && pix < kend;
-                ptr = p.a_src + (long)pix * p.K + m0 + mc * 4;
+                ptr = a_base[i] + (long)a_k[i] * p.K;
             }
             a_reg[i] = ok ? *reinterpret_cast<const f32x4*>(ptr) : f32x4{0.f, 0.f, 0.f, 0.f};
+            // advance by one k-tile
+            a_k[i] += BK;
+            if (MODE != MODE_WGRAD) {
+                const int cin = (MODE == MODE_FWD) ? p.C : p.K;
+                a_c[i] += BK;
+                while (a_c[i] >= cin) {
+                    a_c[i] -= cin;
+                    if (++a_s[i] == p.S) { a_s[i] = 0; ++a_r[i]; }
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
-            const int idx = tid + i * 256;
-            const float* ptr = nullptr;
-            bool ok = b_ok[i];
+            const float* ptr;
+            bool ok = b_ok[i] && b_k[i] < kend;
             if (MODE == MODE_FWD) {
-                const int kg = kb + (idx & 3) * 4;
-                ok = ok && kg < kend;
-                ptr = p.b_src + (long)(n0 + (idx >> 2)) * p.Kg + kg;
+                ptr = b_base[i] + b_k[i];
             } else if (MODE == MODE_DGRAD) {
-                const int krow = idx / (BN / 4);
-                const int nc = idx % (BN / 4);
-                const int kg = kb + krow;
-                const int tap = kg / p.K;
-                const int o = kg - tap * p.K;
-                ok = ok && kg < kend;
-                ptr = p.b_src + ((long)o * (p.R * p.S) + tap) * p.C + n0 + nc * 4;
+                ptr = b_base[i] + ((long)b_o[i] * (p.R * p.S) + b_t[i]) * p.C;
+                b_o[i] += BK;
+                while (b_o[i] >= p.K) { b_o[i] -= p.K; ++b_t[i]; }
             } else {
-                const int krow = idx / (BN / 4);
-                const int pix = kb + krow;
-                const int pp = pix < kend ? pix : 0;
-                const int ow = pp % p.Wo;
-                const int t = pp / p.Wo;
-                const int oh = t % p.Ho;
-                const int n = t / p.Ho;
-                const int ih = oh * p.stride - p.pad + b_r[i];
-                const int iw = ow * p.stride - p.pad + b_s[i];
-                ok = ok && pix < kend && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-                ptr = p.b_src + (((long)n * p.H + ih) * p.W + iw) * p.C + b_c[i];
+                const int ih = b_t[i] * p.stride - p.pad + b_r[i];
+                const int iw = b_o[i] * p.stride - p.pad + b_s[i];
+                ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                ptr = b_base[i] + (((long)b_n[i] * p.H + ih) * p.W + iw) * p.C;
+                b_o[i] += BK;
+                while (b_o[i] >= p.Wo) {
+                    b_o[i] -= p.Wo;
+                    if (++b_t[i] == p.Ho) { b_t[i] = 0; ++b_n[i]; }
+                }
             }
             b_reg[i] = ok ? *reinterpret_cast<const f32x4*>(ptr) : f32x4{0.f, 0.f, 0.f, 0.f};
+            b_k[i] += BK;
         }
     };
 
@@ -201,32 +240,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             const int idx = tid + i * 256;
-            if (MODE == MODE_WGRAD) {
-                const int krow = idx / (BM / 4);
-                const int mc = idx % (BM / 4);
-                *reinterpret_cast<f32x4*>(&As[buf][krow][mc * 4]) = a_reg[i];
-            } else {
-                const int row = idx >> 2, kc = (idx & 3) * 4;
-                As[buf][kc + 0][row] = a_reg[i][0];
-                As[buf][kc + 1][row] = a_reg[i][1];
-                As[buf][kc + 2][row] = a_reg[i][2];
-                As[buf][kc + 3][row] = a_reg[i][3];
-            }
+            if (A_KMAJOR)
+                *reinterpret_cast<f32x4*>(&As[buf][(idx / (BM / 4)) * (BM + 4) + (idx % (BM / 4)) * 4]) = a_reg[i];
+            else
+                *reinterpret_cast<f32x4*>(&As[buf][(idx >> 2) * LDK + (idx & 3) * 4]) = a_reg[i];
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
             const int idx = tid + i * 256;
-            if (MODE == MODE_FWD) {
-                const int row = idx >> 2, kc = (idx & 3) * 4;
-                Bs[buf][kc + 0][row] = b_reg[i][0];
-                Bs[buf][kc + 1][row] = b_reg[i][1];
-                Bs[buf][kc + 2][row] = b_reg[i][2];
-                Bs[buf][kc + 3][row] = b_reg[i][3];
-            } else {
-                const int krow = idx / (BN / 4);
-                const int nc = idx % (BN / 4);
-                *reinterpret_cast<f32x4*>(&Bs[buf][krow][nc * 4]) = b_reg[i];
-            }
+            if (B_KMAJOR)
+                *reinterpret_cast<f32x4*>(&Bs[buf][(idx / (BN / 4)) * (BN + 4) + (idx % (BN / 4)) * 4]) = b_reg[i];
+            else
+                *reinterpret_cast<f32x4*>(&Bs[buf][(idx >> 2) * LDK + (idx & 3) * 4]) = b_reg[i];
         }
     };
 
@@ -238,33 +263,57 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int a_off = wm * (BM / 2) + (lane & 31);
-    const int b_off = wn * (BN / 2) + (lane & 31);
+    const int a_row = wm * (BM / 2) + (lane & 31);
+    const int b_row = wn * (BN / 2) + (lane & 31);
     const int khalf = lane >> 5;
 
     if (nk > 0) {
-        load_tiles(0);
+        load_tiles();
         store_tiles(0);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kt + 1);
+        if (kt + 1 < nk && !(p.dbg & 1)) load_tiles();
+        // fragments: lane (row, khalf) holds tile columns 8*khalf .. 8*khalf+7 of its row
+        float af[TM][8], bf[TN][8];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (A_KMAJOR) {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) af[i][kk] = As[buf][(khalf * 8 + kk) * (BM + 4) + a_row + i * 32];
+            } else {
+                const f32x4* ap = reinterpret_cast<const f32x4*>(&As[buf][(a_row + i * 32) * LDK + khalf * 8]);
+                const f32x4 v0 = ap[0], v1 = ap[1];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) { af[i][kk] = v0[kk]; af[i][4 + kk] = v1[kk]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (B_KMAJOR) {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) bf[j][kk] = Bs[buf][(khalf * 8 + kk) * (BN + 4) + b_row + j * 32];
+            } else {
+                const f32x4* bp = reinterpret_cast<const f32x4*>(&Bs[buf][(b_row + j * 32) * LDK + khalf * 8]);
+                const f32x4 v0 = bp[0], v1 = bp[1];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) { bf[j][kk] = v0[kk]; bf[j][4 + kk] = v1[kk]; }
+            }
+        }
+        // keep every fragment read ahead of the MFMA chain (the scheduler otherwise sinks each read next to
+        // its use and exposes the LDS latency once per k-step)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[buf][kk * 2 + khalf][a_off + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kk * 2 + khalf][b_off + j * 32];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
-        __syncthreads();
+        if (kt + 1 < nk && !(p.dbg & 2)) store_tiles(buf ^ 1);
+        if (!(p.dbg & 4)) __syncthreads();
     }
 
     // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ---------
@@ -296,52 +345,73 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_s part[s*stride + i]
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
-                                     int splits, size_t stride, int accumulate) {
-    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
+// out[i] = (accumulate ? out[i] : 0) + sum_s part[s*stride + i].  256 threads = 64 float4 columns x 4 split-lanes.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                            long n4, int splits, size_t stride, int accumulate) {
+    __shared__ f32x4 red[4][64];
+    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + col;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(part + (size_t)k * stride + i);
-    f32x4* o = reinterpret_cast<f32x4*>(out + i);
+    if (i < n4)
+        for (int k = sl; k < splits; k += 4) s += *reinterpret_cast<const f32x4*>(part + (size_t)k * stride + i * 4);
+    red[sl][col] = s;
+    __syncthreads();
+    if (sl != 0 || i >= n4) return;
+    s += red[1][col] + red[2][col] + red[3][col];
+    f32x4* o = reinterpret_cast<f32x4*>(out + i * 4);
     if (accumulate) s += *o;
     *o = s;
 }
 
 // last launched variant, for the bench's live per-kernel timing: mode * 10 + {0: 128x128, 1: 128x64, 2: 64x64}
 int g_last_variant = -1;
+int g_dbg = 0;
+
+// tile choice: 0 = 128x128, 1 = 128x64, 2 = 64x64 - the largest tile that still yields >= 384 workgroups
+int pick_tile(int Mg, int Ng, long splits) {
+    const long t128 = (long)cdiv(Mg, 128) * cdiv(Ng, 128) * splits;
+    const long t12864 = (long)cdiv(Mg, 128) * cdiv(Ng, 64) * splits;
+    if (Ng > 64 && Mg > 64 && t128 >= 384) return 0;
+    if (Mg > 64 && t12864 >= 384) return 1;
+    return 2;
+}
 
 template <int MODE>
-int launch_igemm(IgemmParams& p, int splits, hipStream_t st) {
-    const long t128 = (long)cdiv(p.Mg, 128) * cdiv(p.Ng, 128) * splits;
-    const long t12864 = (long)cdiv(p.Mg, 128) * cdiv(p.Ng, 64) * splits;
+int launch_igemm(IgemmParams& p, int splits, int tile, hipStream_t st) {
+    p.dbg = g_dbg;
     dim3 block(256);
-    if (p.Ng > 64 && p.Mg > 64 && t128 >= 384) {
+    if (tile == 0) {
         p.tiles_n = cdiv(p.Ng, 128);
         dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, 1, splits);
         hipLaunchKernelGGL((igemm_kernel<MODE, 128, 128>), grid, block, 0, st, p);
-        g_last_variant = MODE * 10 + 0;
-    } else if (p.Mg > 64 && t12864 >= 384) {
+    } else if (tile == 1) {
         p.tiles_n = cdiv(p.Ng, 64);
         dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, 1, splits);
         hipLaunchKernelGGL((igemm_kernel<MODE, 128, 64>), grid, block, 0, st, p);
-        g_last_variant = MODE * 10 + 1;
     } else {
         p.tiles_n = cdiv(p.Ng, 64);
         dim3 grid(cdiv(p.Mg, 64) * p.tiles_n, 1, splits);
         hipLaunchKernelGGL((igemm_kernel<MODE, 64, 64>), grid, block, 0, st, p);
-        g_last_variant = MODE * 10 + 2;
     }
+    g_last_variant = MODE * 10 + tile;
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
+}
+
+template <int MODE>
+int launch_igemm(IgemmParams& p, hipStream_t st) {
+    return launch_igemm<MODE>(p, 1, pick_tile(p.Mg, p.Ng, 1), st);
 }
 
 int run_wgrad(IgemmParams& p, float* dw, int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
     const long out_elems = (long)p.Mg * p.Ng;
     DS6G_CHECK_ARG(out_elems % 4 == 0);
-    // enough independent blocks to fill 256 CUs a few times over, bounded by the workspace
-    const long tiles = (long)cdiv(p.Mg, 64) * cdiv(p.Ng, 64);
-    long splits = (1024 + tiles - 1) / tiles;
+    // the output (a weight tensor) has few tiles and the reduction (pixels) is long: split K until the grid
+    // holds ~6 workgroups per CU (latency hiding needs the occupancy), bounded by the workspace and by
+    // >= 4 k-tiles per split
+    const int tile = (p.Mg >= 128) ? 1 : 2;
+    const long tiles = (long)cdiv(p.Mg, tile == 1 ? 128 : 64) * cdiv(p.Ng, 64);
+    long splits = (1536 + tiles - 1) / tiles;
     const long max_by_k = (p.Kg + 4 * BK - 1) / (4 * BK);
     if (splits > max_by_k) splits = max_by_k;
     const long max_by_ws = (long)(ws_bytes / (out_elems * sizeof(float)));
@@ -353,14 +423,13 @@ int run_wgrad(IgemmParams& p, float* dw, int accumulate, float* ws, size_t ws_by
     p.split_stride = (size_t)out_elems;
     if (splits == 1 && !accumulate) {
         p.out = dw;
-        return launch_igemm<MODE_WGRAD>(p, 1, st);
+        return launch_igemm<MODE_WGRAD>(p, 1, tile, st);
     }
     DS6G_CHECK_ARG(ws != nullptr && (size_t)splits * out_elems * sizeof(float) <= ws_bytes);
     p.out = ws;
-    int rc = launch_igemm<MODE_WGRAD>(p, (int)splits, st);
+    int rc = launch_igemm<MODE_WGRAD>(p, (int)splits, tile, st);
     if (rc) return rc;
-    const int thr = 256;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(out_elems / 4, thr)), dim3(thr), 0, st, ws, dw, out_elems,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(out_elems / 4, 64)), dim3(256), 0, st, ws, dw, out_elems / 4,
                        (int)splits, (size_t)out_elems, accumulate);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
@@ -379,6 +448,7 @@ void fill_conv(IgemmParams& p, int N, int H, int W, int C, int K, int R, int S, 
 extern "C" {
 
 int ds6g_last_igemm_variant(void) { return g_last_variant; }
+int ds6g_set_debug_flags(int flags) { g_dbg = flags; return 0; }
 
 int ds6g_conv2d_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int K, int R,
                     int S, int stride, int pad, void* stream) {
@@ -388,7 +458,7 @@ int ds6g_conv2d_fwd(const float* x, const float* w, float* y, int N, int H, int 
     fill_conv(p, N, H, W, C, K, R, S, stride, pad);
     p.a_src = x; p.b_src = w; p.out = y;
     p.Mg = N * p.Ho * p.Wo; p.Ng = K; p.Kg = R * S * C;
-    return launch_igemm<MODE_FWD>(p, 1, (hipStream_t)stream);
+    return launch_igemm<MODE_FWD>(p, (hipStream_t)stream);
 }
 
 int ds6g_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R,
@@ -399,7 +469,7 @@ int ds6g_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
     fill_conv(p, N, H, W, C, K, R, S, stride, pad);
     p.a_src = dy; p.b_src = w; p.out = dx; p.accumulate = accumulate;
     p.Mg = N * H * W; p.Ng = C; p.Kg = R * S * K;
-    return launch_igemm<MODE_DGRAD>(p, 1, (hipStream_t)stream);
+    return launch_igemm<MODE_DGRAD>(p, (hipStream_t)stream);
 }
 
 int ds6g_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R,
@@ -425,7 +495,7 @@ int ds6g_linear_fwd(const float* x, const float* w, const float* bias, float* y,
     p.drop_scale = 1.f / (1.f - drop_p);
     p.seed = seed; p.seed_off = seed_off;
     p.Mg = M; p.Ng = N; p.Kg = K;
-    return launch_igemm<MODE_FWD>(p, 1, (hipStream_t)stream);
+    return launch_igemm<MODE_FWD>(p, (hipStream_t)stream);
 }
 
 // dx[M][K] (+)= (dy[M][N] @ w[N][K]) * (mask_src > 0)
@@ -437,7 +507,7 @@ int ds6g_linear_dgrad(const float* dy, const float* w, float* dx, int M, int N, 
     fill_conv(p, M, 1, 1, K, N, 1, 1, 1, 0);
     p.a_src = dy; p.b_src = w; p.out = dx; p.mask_src = mask_src; p.accumulate = accumulate;
     p.Mg = M; p.Ng = K; p.Kg = N;
-    return launch_igemm<MODE_DGRAD>(p, 1, (hipStream_t)stream);
+    return launch_igemm<MODE_DGRAD>(p, (hipStream_t)stream);
 }
 
 // dw[N][K] (+)= dy[M][N]^T @ x[M][K]

@@ -9,7 +9,10 @@
 
 namespace {
 
-constexpr int BN_ROWS_PER_THREAD = 64;
+constexpr int BN_ROWS_PER_THREAD = 16;
+// finalize kernels: 256 threads = 8 columns x 32 partial-groups; each group strides over the row-block partials
+constexpr int FIN_COLS = 8;
+constexpr int FIN_GROUPS = 32;
 
 // partial[blk][0][c] = sum_rows a(r,c), partial[blk][1][c] = sum_rows b(r,c) in fp64.
 // MODE 0: a = x, b = x*x.   MODE 1: a = dyeff, b = dyeff * xhat  (BN backward)
@@ -64,15 +67,27 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
 }
 
 // training statistics: mean / invstd from partials, running-stat update
-__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int nblk, long M, int C, float eps,
-                                         float momentum, float* __restrict__ mean, float* __restrict__ invstd,
-                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ partial, int nblk, long M,
+                                                                int C, float eps, float momentum,
+                                                                float* __restrict__ mean, float* __restrict__ invstd,
+                                                                float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var) {
+    __shared__ double red[2][FIN_GROUPS][FIN_COLS];
+    const int cl = threadIdx.x & (FIN_COLS - 1), g = threadIdx.x / FIN_COLS;
+    const int c = blockIdx.x * FIN_COLS + cl;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += partial[(size_t)b * 2 * C + c];
-        q += partial[(size_t)b * 2 * C + C + c];
+    if (c < C)
+        for (int b = g; b < nblk; b += FIN_GROUPS) {
+            s += partial[(size_t)b * 2 * C + c];
+            q += partial[(size_t)b * 2 * C + C + c];
+        }
+    red[0][g][cl] = s;
+    red[1][g][cl] = q;
+    __syncthreads();
+    if (g != 0 || c >= C) return;
+    for (int gg = 1; gg < FIN_GROUPS; ++gg) {
+        s += red[0][gg][cl];
+        q += red[1][gg][cl];
     }
     const double mu = s / (double)M;
     double var = q / (double)M - mu * mu;
@@ -120,16 +135,27 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // dgamma/dbeta and the per-channel coefficients of dx = a * (dyeff - b - xhat * cc)
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, long M, int C,
-                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ coef, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, long M,
+                                                              int C, const float* __restrict__ gamma,
+                                                              const float* __restrict__ invstd,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coef, int accumulate) {
+    __shared__ double red[2][FIN_GROUPS][FIN_COLS];
+    const int cl = threadIdx.x & (FIN_COLS - 1), g = threadIdx.x / FIN_COLS;
+    const int c = blockIdx.x * FIN_COLS + cl;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += partial[(size_t)b * 2 * C + c];
-        s2 += partial[(size_t)b * 2 * C + C + c];
+    if (c < C)
+        for (int b = g; b < nblk; b += FIN_GROUPS) {
+            s1 += partial[(size_t)b * 2 * C + c];
+            s2 += partial[(size_t)b * 2 * C + C + c];
+        }
+    red[0][g][cl] = s1;
+    red[1][g][cl] = s2;
+    __syncthreads();
+    if (g != 0 || c >= C) return;
+    for (int gg = 1; gg < FIN_GROUPS; ++gg) {
+        s1 += red[0][gg][cl];
+        s2 += red[1][gg][cl];
     }
     if (accumulate) {
         dgamma[c] += (float)s2;
@@ -278,12 +304,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // out[c] (+)= sum_b partial[b][c]   (generic column finalize over row-block partials)
-__global__ void col_finalize_kernel(const float* __restrict__ partial, int nblk, int ncol, float* __restrict__ out0,
-                                    float* __restrict__ out1, int split_at, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncol) return;
+__global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restrict__ partial, int nblk, int ncol,
+                                                           float* __restrict__ out0, float* __restrict__ out1,
+                                                           int split_at, int accumulate) {
+    __shared__ double red[FIN_GROUPS][FIN_COLS];
+    const int cl = threadIdx.x & (FIN_COLS - 1), g = threadIdx.x / FIN_COLS;
+    const int c = blockIdx.x * FIN_COLS + cl;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * ncol + c];
+    if (c < ncol)
+        for (int b = g; b < nblk; b += FIN_GROUPS) s += (double)partial[(size_t)b * ncol + c];
+    red[g][cl] = s;
+    __syncthreads();
+    if (g != 0 || c >= ncol) return;
+    for (int gg = 1; gg < FIN_GROUPS; ++gg) s += red[gg][cl];
     float* dst = (c < split_at) ? (out0 + c) : (out1 + (c - split_at));
     *dst = accumulate ? (*dst + (float)s) : (float)s;
 }
@@ -336,7 +369,7 @@ int ds6g_bn_stats(const float* x, long M, int C, float eps, float momentum, floa
     hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, x, nullptr, nullptr,
                        nullptr, nullptr, M, C, rpb, partial);
     DS6G_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, nblk,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk,
                        M, C, eps, momentum, mean, invstd, running_mean, running_var);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
@@ -380,7 +413,7 @@ int ds6g_bn_bwd(const float* dy, const float* y_mask, const float* x, const floa
     hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, x, dy, y_mask, mean,
                        invstd, M, C, rpb, partial);
     DS6G_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, nblk, M,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk, M,
                        C, gamma, invstd, dgamma, dbeta, coef, accumulate_param_grads);
     DS6G_LAUNCH_CHECK();
     const long total4 = M * C / 4;
@@ -431,20 +464,21 @@ int ds6g_layernorm_bwd(const float* dy, const float* x, const float* mean, const
         default: DS6G_CHECK_ARG(!"LayerNorm width must be 64/128/256/512");
     }
     DS6G_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_finalize_kernel, dim3(cdiv(2 * C, 64)), dim3(64), 0, st, partial, nblk, 2 * C, dgamma,
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(cdiv(2 * C, FIN_COLS)), dim3(256), 0, st, partial, nblk, 2 * C, dgamma,
                        dbeta, C, accumulate_param_grads);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }
 
-size_t ds6g_colsum_workspace_bytes(long M, int C) { return (size_t)cdiv(M, 256) * C * sizeof(float); }
+constexpr int COLSUM_ROWS = 32;
+size_t ds6g_colsum_workspace_bytes(long M, int C) { return (size_t)cdiv(M, COLSUM_ROWS) * C * sizeof(float); }
 
 // out[c] (+)= sum_r x[r][c]
 int ds6g_colsum(const float* x, long M, int C, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(x && out && ws && C % 4 == 0 && M > 0);
     DS6G_CHECK_ARG(ws_bytes >= ds6g_colsum_workspace_bytes(M, C));
-    const int rpb = 256;
+    const int rpb = COLSUM_ROWS;
     const int nblk = cdiv(M, rpb);
     const int cols_per_pass = (C / 4) < 256 ? (C / 4) : 256;
     DS6G_CHECK_ARG(256 % cols_per_pass == 0);
@@ -452,7 +486,7 @@ int ds6g_colsum(const float* x, long M, int C, float* out, int accumulate, void*
     float* partial = (float*)ws;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), lds, (hipStream_t)stream, x, M, C, rpb, partial);
     DS6G_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, nblk, C, out,
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, out,
                        out, C, accumulate);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;

@@ -26,6 +26,8 @@ int ds6g_version(void);
 /* which implicit-GEMM instantiation the last conv/linear call launched: mode*10 + tile
  * (mode 0 fwd, 1 dgrad, 2 wgrad; tile 0 128x128, 1 128x64, 2 64x64).  Bench instrumentation only. */
 int ds6g_last_igemm_variant(void);
+/* ablation switches for kernel timing experiments (results become wrong); 0 = normal operation */
+int ds6g_set_debug_flags(int flags);
 
 /* ---- igemm.hip : Conv2d / Linear as implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------
  * Conv2d(bias=False) of the ResNet trunks: model2_seq.py:495,500,505 (7x7/2 stems), :510-512,
