@@ -8,14 +8,17 @@
 // 565-567 (ResNet trunks), :83-90,:97-99,:109,:121-126 (GPT linears), :422-425,:863-869.
 //
 // Tiling: 256 threads = 4 waves (2x2); block tile BM x BN, BK = 16.  Operands are staged in LDS
-// row-major [row][BK+4] (80-B rows).  The MFMA k-order inside a tile is permuted - step kk of lane
-// half h consumes tile column 8h+kk for BOTH operands - so a lane's 8 k-values are 32 contiguous
-// bytes: two ds_read_b128 per 32-row fragment, conflict-free at the 20-float row stride, all issued
-// before the 8-step MFMA chain (one exposed LDS latency per k-tile instead of one per k-step).
-// Global loads are 16 B per lane, register-prefetched one k-tile ahead (single barrier per k-tile,
-// two LDS buffers).  Row-contiguous sources (both wgrad operands, dgrad weights) keep a k-major
-// image [k][rows+4] instead: their loads stay fully coalesced (whole 256/512-B rows per wave),
-// stores are ds_write_b128 and a fragment is 8 conflict-free ds_read_b32, again issued up front.
+// row-major.  The MFMA k-order inside a tile is permuted - step kk of lane half h consumes tile
+// column 8h+kk for BOTH operands - so a lane's 8 k-values are two 16-B chunks: two ds_read_b128 per
+// 32-row fragment, all issued before the 8-step MFMA chain (one exposed LDS latency per k-tile
+// instead of one per k-step).
+// Operands go global -> LDS directly (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction, no VGPR
+// staging, no ds_write), one k-tile ahead, two LDS buffers, one barrier per k-tile; out-of-range lanes
+// (conv halo, tile / k tails) point past the buffer descriptor and the DMA writes zeros for them.
+// K-contiguous sources use a [row][16] image whose 16-B chunk index is XOR-swizzled with (row>>2)&3 on
+// the source address (the DMA destination is lane-linear) - fragment reads stay conflict-free
+// ds_read_b128.  Row-contiguous sources (both wgrad operands, dgrad weights) use a k-major [16][rows]
+// image: whole 256/512-B rows per wave-instruction and 8 conflict-free ds_read_b32 per fragment.
 #include "common.h"
 
 namespace {
@@ -42,28 +45,62 @@ struct IgemmParams {
     int k_per_split;     // multiple of 16
     size_t split_stride; // elements between split-K slabs
     int tiles_n;
+    unsigned a_bytes, b_bytes;  // sizes of the a_src / b_src tensors (buffer descriptors: OOB lanes read zeros)
     int dbg;  // ablation flags (timing experiments only): 1 skip in-loop global loads, 2 skip LDS stores, 4 skip barrier
 };
 
 constexpr int BK = 16;
 
+// One LDS-DMA piece: 64 lanes x 16 B land at lds_base + lane*16 (lane-linear); a lane whose byte offset is
+// >= the descriptor's size (OOB_OFF) gets ZEROS written (measured on gfx950: tools/t_glds.hip) - that is how
+// conv halos, tile tails and k tails are zero-filled without touching a VGPR.
+#define OOB_OFF 0x80000000u
+typedef __attribute__((address_space(3))) void lds_void;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor: base, stride 0, num_records = bytes, DATA_FORMAT 32 (gfx9 raw buffer)
+__device__ __forceinline__ i32x4 make_srd(const void* ptr, unsigned bytes) {
+    const unsigned long a = (unsigned long)ptr;
+    return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+
+// The DMA is issued from inline asm on purpose: hipcc treats a builtin LDS-DMA as aliasing every LDS read and
+// drains vmcnt before the fragment reads of the OTHER buffer, which serialises DMA and MFMA.  From asm the
+// compiler does not see the load; its completion is waited for by the explicit `s_waitcnt vmcnt(0)` ahead of
+// the barrier that precedes the reads.  M0 (LDS destination base) is saved/restored inside the statement.
+__device__ __forceinline__ void dma16(const i32x4 srd, unsigned lds_byte_addr, unsigned voffset) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voffset), "s"(lds_byte_addr), "s"(srd)
+        : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return (unsigned)(unsigned long)(lds_void*)p;
+}
+
 template <int MODE, int BM, int BN>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
-    constexpr int LDK = BK + 4;  // 20 floats: 16-B aligned rows, conflict-free b128 fragment reads
     constexpr int TM = BM / 64;  // 32x32 MFMA tiles per wave along M (wave grid 2x2)
     constexpr int TN = BN / 64;
-    constexpr int A_LD = BM * 4 / 256;  // float4 loads per thread per k-tile
+    constexpr int A_LD = BM * 4 / 256;  // 16-B DMA pieces per thread per k-tile
     constexpr int B_LD = BN * 4 / 256;
-    constexpr bool A_KMAJOR = (MODE == MODE_WGRAD);                 // A source contiguous along rows (m)
-    constexpr bool B_KMAJOR = (MODE != MODE_FWD);                   // B source contiguous along rows (n)
-    constexpr int A_FLOATS = A_KMAJOR ? BK * (BM + 4) : BM * LDK;
-    constexpr int B_FLOATS = B_KMAJOR ? BK * (BN + 4) : BN * LDK;
-    __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
-    __shared__ __attribute__((aligned(16))) float Bs[2][B_FLOATS];
+    constexpr bool A_KMAJOR = (MODE == MODE_WGRAD);  // A source contiguous along rows (m): image [k][BM]
+    constexpr bool B_KMAJOR = (MODE != MODE_FWD);    // B source contiguous along rows (n): image [k][BN]
+    // K-contiguous sources: image [row][16] (64-B rows, no padding - the DMA destination is lane-linear) with the
+    // 16-B chunk index XOR-swizzled by (row>>2)&3 on the SOURCE side; readers apply the same XOR.
+    // four separate objects (not [2][..] arrays): the compiler must be able to prove that the fragment reads of
+    // one buffer do not alias the DMA in flight into the other, or it drains vmcnt before every read
+    __shared__ __attribute__((aligned(16))) float As0[BM * BK];
+    __shared__ __attribute__((aligned(16))) float As1[BM * BK];
+    __shared__ __attribute__((aligned(16))) float Bs0[BN * BK];
+    __shared__ __attribute__((aligned(16))) float Bs1[BN * BK];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware tile order: hardware deals consecutive workgroups round-robin over the 8 XCDs (each
     // with a private L2); remap so that every XCD walks a contiguous run of tiles (tile_n fastest),
@@ -82,22 +119,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int kend = (MODE == MODE_WGRAD) ? min(p.Kg, kbegin + p.k_per_split) : p.Kg;
     const int nk = (kend - kbegin + BK - 1) / BK;
 
-    // ---- per-thread load state.  All index arithmetic that needs a division happens ONCE here; the k-loop
-    // only advances (channel, tap) / (pixel) counters by BK with compare-and-wrap.
-    // A operand
-    const float* a_base[A_LD];   // FWD/DGRAD: image base of this row; WGRAD: column base
+    const i32x4 a_rsrc = make_srd(p.a_src, p.a_bytes);
+    const i32x4 b_rsrc = make_srd(p.b_src, p.b_bytes);
+
+    // ---- per-thread DMA state.  Everything that needs a division happens ONCE here; the k-loop only advances
+    // (channel, tap) / pixel counters by BK with compare-and-wrap.  Offsets are in floats (tensors < 2 GB).
+    unsigned a_base[A_LD];       // FWD/DGRAD: image base of this row; WGRAD: column base
     int a_y[A_LD], a_x[A_LD];    // FWD: ih0, iw0 ; DGRAD: h+pad, w+pad
-    int a_c[A_LD], a_r[A_LD], a_s[A_LD], a_k[A_LD];  // running channel / tap / global-k of this thread's chunk
+    int a_c[A_LD], a_r[A_LD], a_s[A_LD], a_k[A_LD];
     bool a_ok[A_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
         const int idx = tid + i * 256;
         if (MODE == MODE_FWD || MODE == MODE_DGRAD) {
-            const int m = m0 + (idx >> 2);
+            const int row = idx >> 2;
+            const int m = m0 + row;
             a_ok[i] = m < p.Mg;
             const int mm = a_ok[i] ? m : 0;
             const int cin = (MODE == MODE_FWD) ? p.C : p.K;
-            const int kg = (idx & 3) * 4;
+            const int kg = ((idx & 3) ^ ((row >> 2) & 3)) * 4;  // swizzled source chunk
             a_k[i] = kg;
             const int tap = kg / cin;
             a_c[i] = kg - tap * cin;
@@ -110,7 +150,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                 const int n = t / p.Ho;
                 a_y[i] = oh * p.stride - p.pad;
                 a_x[i] = ow * p.stride - p.pad;
-                a_base[i] = p.a_src + (long)n * p.H * p.W * p.C;
+                a_base[i] = (unsigned)n * (unsigned)(p.H * p.W * p.C);
             } else {
                 const int w_ = mm % p.W;
                 const int t = mm / p.W;
@@ -118,18 +158,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                 const int n = t / p.H;
                 a_y[i] = h_ + p.pad;
                 a_x[i] = w_ + p.pad;
-                a_base[i] = p.a_src + (long)n * p.Ho * p.Wo * p.K;
+                a_base[i] = (unsigned)n * (unsigned)(p.Ho * p.Wo * p.K);
             }
         } else {
-            const int mc = idx % (BM / 4);  // row-contiguous source: a wave reads whole rows
+            const int mc = idx % (BM / 4);
             a_ok[i] = (m0 + mc * 4) < p.Mg;
             a_k[i] = kbegin + idx / (BM / 4);  // pixel
-            a_base[i] = p.a_src + m0 + mc * 4;
+            a_base[i] = (unsigned)(m0 + mc * 4);
             a_y[i] = a_x[i] = a_c[i] = a_r[i] = a_s[i] = 0;
         }
     }
-    // B operand
-    const float* b_base[B_LD];
+    unsigned b_base[B_LD];
     int b_r[B_LD], b_s[B_LD];      // WGRAD: fixed tap of this thread's column chunk
     int b_k[B_LD];                 // running global k (FWD/DGRAD) or pixel (WGRAD)
     int b_o[B_LD], b_t[B_LD];      // DGRAD: running (out channel, tap); WGRAD: running (ow, oh)
@@ -140,16 +179,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         const int idx = tid + i * 256;
         b_r[i] = b_s[i] = b_o[i] = b_t[i] = b_n[i] = 0;
         if (MODE == MODE_FWD) {
-            b_ok[i] = (n0 + (idx >> 2)) < p.Ng;
-            b_k[i] = (idx & 3) * 4;
-            b_base[i] = p.b_src + (long)(n0 + (idx >> 2)) * p.Kg;
+            const int row = idx >> 2;
+            b_ok[i] = (n0 + row) < p.Ng;
+            b_k[i] = ((idx & 3) ^ ((row >> 2) & 3)) * 4;
+            b_base[i] = (unsigned)(n0 + row) * (unsigned)p.Kg;
         } else if (MODE == MODE_DGRAD) {
             b_ok[i] = (n0 + (idx % (BN / 4)) * 4) < p.Ng;
             const int kg = idx / (BN / 4);
             b_k[i] = kg;
             b_t[i] = kg / p.K;
             b_o[i] = kg - b_t[i] * p.K;
-            b_base[i] = p.b_src + n0 + (idx % (BN / 4)) * 4;
+            b_base[i] = (unsigned)(n0 + (idx % (BN / 4)) * 4);
         } else {
             const int ncol = n0 + (idx % (BN / 4)) * 4;
             b_ok[i] = ncol < p.Ng;
@@ -157,7 +197,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             const int tap = nn / p.C;
             b_r[i] = tap / p.S;
             b_s[i] = tap - b_r[i] * p.S;
-            b_base[i] = p.b_src + (nn - tap * p.C);
+            b_base[i] = (unsigned)(nn - tap * p.C);
             const int pix = kbegin + idx / (BN / 4);
             b_k[i] = pix;
             const int pp = pix < p.Kg ? pix : 0;
@@ -168,18 +208,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         }
     }
 
-    f32x4 a_reg[A_LD], b_reg[B_LD];
-
-    // loads the NEXT k-tile (state is advanced by BK afterwards): must be called for kt = 0, 1, 2, ... in order
-    auto load_tiles = [&]() {
+    // issues the DMA of the NEXT k-tile into LDS buffer `buf` (state is advanced by BK afterwards)
+    auto issue_tiles = [&](float* Ad, float* Bd) {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            const float* ptr;
+            unsigned off;
             bool ok = a_ok[i] && a_k[i] < kend;
             if (MODE == MODE_FWD) {
                 const int ih = a_y[i] + a_r[i], iw = a_x[i] + a_s[i];
                 ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-                ptr = a_base[i] + ((long)ih * p.W + iw) * p.C + a_c[i];
+                off = a_base[i] + (unsigned)((ih * p.W + iw) * p.C + a_c[i]);
             } else if (MODE == MODE_DGRAD) {
                 const int th = a_y[i] - a_r[i], tw = a_x[i] - a_s[i];
                 int oh = th, ow = tw;
@@ -194,12 +232,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                     okk = okk && (oh * p.stride == th) && (ow * p.stride == tw);
                 }
                 ok = ok && okk && oh < p.Ho && ow < p.Wo;
-                ptr = a_base[i] + ((long)oh * p.Wo + ow) * p.K + a_c[i];
+                off = a_base[i] + (unsigned)((oh * p.Wo + ow) * p.K + a_c[i]);
             } else {
-                ptr = a_base[i] + (long)a_k[i] * p.K;
+                off = a_base[i] + (unsigned)a_k[i] * (unsigned)p.K;
             }
-            a_reg[i] = ok ? *reinterpret_cast<const f32x4*>(ptr) : f32x4{0.f, 0.f, 0.f, 0.f};
-            // advance by one k-tile
+            dma16(a_rsrc, lds_addr(Ad) + (unsigned)(i * 256 + wave * 64) * 16u, ok ? off * 4u : OOB_OFF);
             a_k[i] += BK;
             if (MODE != MODE_WGRAD) {
                 const int cin = (MODE == MODE_FWD) ? p.C : p.K;
@@ -212,46 +249,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
-            const float* ptr;
+            unsigned off;
             bool ok = b_ok[i] && b_k[i] < kend;
             if (MODE == MODE_FWD) {
-                ptr = b_base[i] + b_k[i];
+                off = b_base[i] + (unsigned)b_k[i];
             } else if (MODE == MODE_DGRAD) {
-                ptr = b_base[i] + ((long)b_o[i] * (p.R * p.S) + b_t[i]) * p.C;
+                off = b_base[i] + (unsigned)((b_o[i] * (p.R * p.S) + b_t[i]) * p.C);
                 b_o[i] += BK;
                 while (b_o[i] >= p.K) { b_o[i] -= p.K; ++b_t[i]; }
             } else {
                 const int ih = b_t[i] * p.stride - p.pad + b_r[i];
                 const int iw = b_o[i] * p.stride - p.pad + b_s[i];
                 ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-                ptr = b_base[i] + (((long)b_n[i] * p.H + ih) * p.W + iw) * p.C;
+                off = b_base[i] + (unsigned)(((b_n[i] * p.H + ih) * p.W + iw) * p.C);
                 b_o[i] += BK;
                 while (b_o[i] >= p.Wo) {
                     b_o[i] -= p.Wo;
                     if (++b_t[i] == p.Ho) { b_t[i] = 0; ++b_n[i]; }
                 }
             }
-            b_reg[i] = ok ? *reinterpret_cast<const f32x4*>(ptr) : f32x4{0.f, 0.f, 0.f, 0.f};
+            dma16(b_rsrc, lds_addr(Bd) + (unsigned)(i * 256 + wave * 64) * 16u, ok ? off * 4u : OOB_OFF);
             b_k[i] += BK;
-        }
-    };
-
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int idx = tid + i * 256;
-            if (A_KMAJOR)
-                *reinterpret_cast<f32x4*>(&As[buf][(idx / (BM / 4)) * (BM + 4) + (idx % (BM / 4)) * 4]) = a_reg[i];
-            else
-                *reinterpret_cast<f32x4*>(&As[buf][(idx >> 2) * LDK + (idx & 3) * 4]) = a_reg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int idx = tid + i * 256;
-            if (B_KMAJOR)
-                *reinterpret_cast<f32x4*>(&Bs[buf][(idx / (BN / 4)) * (BN + 4) + (idx % (BN / 4)) * 4]) = b_reg[i];
-            else
-                *reinterpret_cast<f32x4*>(&Bs[buf][(idx >> 2) * LDK + (idx & 3) * 4]) = b_reg[i];
         }
     };
 
@@ -266,25 +284,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int a_row = wm * (BM / 2) + (lane & 31);
     const int b_row = wn * (BN / 2) + (lane & 31);
     const int khalf = lane >> 5;
+    const int swz = ((lane & 31) >> 2) & 3;          // (row >> 2) & 3 of every fragment row of this lane
+    const int p0 = ((2 * khalf) ^ swz) * 4, p1 = ((2 * khalf + 1) ^ swz) * 4;
 
-    if (nk > 0) {
-        load_tiles();
-        store_tiles(0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk && !(p.dbg & 1)) load_tiles();
+    // one k-tile: start the DMA of the next tile into (An, Bn), multiply the tile resident in (Ac, Bc)
+    auto k_step = [&](const float* Ac, const float* Bc, float* An, float* Bn, bool more) {
+        if (more && !(p.dbg & 1)) issue_tiles(An, Bn);
         // fragments: lane (row, khalf) holds tile columns 8*khalf .. 8*khalf+7 of its row
         float af[TM][8], bf[TN][8];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if (A_KMAJOR) {
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) af[i][kk] = As[buf][(khalf * 8 + kk) * (BM + 4) + a_row + i * 32];
+                for (int kk = 0; kk < 8; ++kk) af[i][kk] = Ac[(khalf * 8 + kk) * BM + a_row + i * 32];
             } else {
-                const f32x4* ap = reinterpret_cast<const f32x4*>(&As[buf][(a_row + i * 32) * LDK + khalf * 8]);
-                const f32x4 v0 = ap[0], v1 = ap[1];
+                const float* rp = &Ac[(a_row + i * 32) * BK];
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp + p0), v1 = *reinterpret_cast<const f32x4*>(rp + p1);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) { af[i][kk] = v0[kk]; af[i][4 + kk] = v1[kk]; }
             }
@@ -293,10 +308,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         for (int j = 0; j < TN; ++j) {
             if (B_KMAJOR) {
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) bf[j][kk] = Bs[buf][(khalf * 8 + kk) * (BN + 4) + b_row + j * 32];
+                for (int kk = 0; kk < 8; ++kk) bf[j][kk] = Bc[(khalf * 8 + kk) * BN + b_row + j * 32];
             } else {
-                const f32x4* bp = reinterpret_cast<const f32x4*>(&Bs[buf][(b_row + j * 32) * LDK + khalf * 8]);
-                const f32x4 v0 = bp[0], v1 = bp[1];
+                const float* rp = &Bc[(b_row + j * 32) * BK];
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp + p0), v1 = *reinterpret_cast<const f32x4*>(rp + p1);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) { bf[j][kk] = v0[kk]; bf[j][4 + kk] = v1[kk]; }
             }
@@ -312,8 +327,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk && !(p.dbg & 2)) store_tiles(buf ^ 1);
+        // the DMA of the next tile must have landed before any wave reads it, and every wave must be done reading
+        // the current buffers before the DMA after next overwrites them.  sched_barrier pins the wait BEHIND the
+        // MFMA chain (an asm wait does not order register-only instructions) so the DMA flies under the MFMAs.
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(p.dbg & 4)) __syncthreads();
+    };
+
+    if (nk > 0 && !(p.dbg & 16)) issue_tiles(As0, Bs0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        k_step(As0, Bs0, As1, Bs1, kt + 1 < nk);
+        if (kt + 1 < nk) k_step(As1, Bs1, As0, Bs0, kt + 2 < nk);
     }
 
     // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ---------
@@ -323,7 +350,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-            if (col >= p.Ng) continue;
+            if (col >= p.Ng || ((p.dbg & 8) && (i | j))) continue;
             const float bias = (MODE != MODE_WGRAD && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -443,6 +470,17 @@ void fill_conv(IgemmParams& p, int N, int H, int W, int C, int K, int R, int S, 
     p.drop_scale = 1.f;
 }
 
+// byte sizes of the three tensors of a conv (for the buffer descriptors); all must stay below the OOB sentinel
+struct ConvBytes { size_t x, y, w; bool ok; };
+ConvBytes conv_bytes(const IgemmParams& p) {
+    ConvBytes b;
+    b.x = (size_t)p.N * p.H * p.W * p.C * sizeof(float);
+    b.y = (size_t)p.N * p.Ho * p.Wo * p.K * sizeof(float);
+    b.w = (size_t)p.K * p.R * p.S * p.C * sizeof(float);
+    b.ok = b.x < OOB_OFF && b.y < OOB_OFF && b.w < OOB_OFF;
+    return b;
+}
+
 }  // namespace
 
 extern "C" {
@@ -457,6 +495,9 @@ int ds6g_conv2d_fwd(const float* x, const float* w, float* y, int N, int H, int 
     IgemmParams p;
     fill_conv(p, N, H, W, C, K, R, S, stride, pad);
     p.a_src = x; p.b_src = w; p.out = y;
+    const ConvBytes cb = conv_bytes(p);
+    DS6G_CHECK_ARG(cb.ok);
+    p.a_bytes = (unsigned)cb.x; p.b_bytes = (unsigned)cb.w;
     p.Mg = N * p.Ho * p.Wo; p.Ng = K; p.Kg = R * S * C;
     return launch_igemm<MODE_FWD>(p, (hipStream_t)stream);
 }
@@ -468,6 +509,9 @@ int ds6g_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
     IgemmParams p;
     fill_conv(p, N, H, W, C, K, R, S, stride, pad);
     p.a_src = dy; p.b_src = w; p.out = dx; p.accumulate = accumulate;
+    const ConvBytes cb = conv_bytes(p);
+    DS6G_CHECK_ARG(cb.ok);
+    p.a_bytes = (unsigned)cb.y; p.b_bytes = (unsigned)cb.w;
     p.Mg = N * H * W; p.Ng = C; p.Kg = R * S * K;
     return launch_igemm<MODE_DGRAD>(p, (hipStream_t)stream);
 }
@@ -479,6 +523,9 @@ int ds6g_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
     IgemmParams p;
     fill_conv(p, N, H, W, C, K, R, S, stride, pad);
     p.a_src = dy; p.b_src = x;
+    const ConvBytes cb = conv_bytes(p);
+    DS6G_CHECK_ARG(cb.ok);
+    p.a_bytes = (unsigned)cb.y; p.b_bytes = (unsigned)cb.x;
     p.Mg = K; p.Ng = R * S * C; p.Kg = N * p.Ho * p.Wo;
     return run_wgrad(p, dw, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -494,6 +541,9 @@ int ds6g_linear_fwd(const float* x, const float* w, const float* bias, float* y,
     p.drop_thr = ds6g_drop_threshold(drop_p);
     p.drop_scale = 1.f / (1.f - drop_p);
     p.seed = seed; p.seed_off = seed_off;
+    const ConvBytes cb = conv_bytes(p);
+    DS6G_CHECK_ARG(cb.ok);
+    p.a_bytes = (unsigned)cb.x; p.b_bytes = (unsigned)cb.w;
     p.Mg = M; p.Ng = N; p.Kg = K;
     return launch_igemm<MODE_FWD>(p, (hipStream_t)stream);
 }
@@ -506,6 +556,9 @@ int ds6g_linear_dgrad(const float* dy, const float* w, float* dx, int M, int N, 
     IgemmParams p;
     fill_conv(p, M, 1, 1, K, N, 1, 1, 1, 0);
     p.a_src = dy; p.b_src = w; p.out = dx; p.mask_src = mask_src; p.accumulate = accumulate;
+    const ConvBytes cb = conv_bytes(p);
+    DS6G_CHECK_ARG(cb.ok);
+    p.a_bytes = (unsigned)cb.y; p.b_bytes = (unsigned)cb.w;
     p.Mg = M; p.Ng = K; p.Kg = N;
     return launch_igemm<MODE_DGRAD>(p, (hipStream_t)stream);
 }
@@ -518,6 +571,9 @@ int ds6g_linear_wgrad(const float* x, const float* dy, float* dw, int M, int N, 
     IgemmParams p;
     fill_conv(p, M, 1, 1, K, N, 1, 1, 1, 0);
     p.a_src = dy; p.b_src = x;
+    const ConvBytes cb = conv_bytes(p);
+    DS6G_CHECK_ARG(cb.ok);
+    p.a_bytes = (unsigned)cb.y; p.b_bytes = (unsigned)cb.x;
     p.Mg = N; p.Ng = K; p.Kg = M;
     return run_wgrad(p, dw, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -17,7 +17,7 @@ SHAPES = [  # name, N, H, W, C, K, R, stride, pad
     ("l4_3x3", N, 8, 8, 512, 512, 3, 1, 1),
     ("l4_1x1s2", N, 16, 16, 256, 512, 1, 2, 0),
 ]
-LIN = [("gpt1_qkv", 11544, 64, 64), ("gpt1_fc1", 11544, 256, 64), ("gpt2_fc1", 11544, 512, 128),
+LIN = [("bal768", 12288, 1024, 512), ("bal768k4096", 12288, 1024, 4096), ("bal1536", 12288, 2048, 512), ("gpt1_qkv", 11544, 64, 64), ("gpt1_fc1", 11544, 256, 64), ("gpt2_fc1", 11544, 512, 128),
        ("gpt3_fc1", 11544, 1024, 256), ("gpt4_qkv", 11544, 512, 512), ("gpt4_fc1", 11544, 2048, 512),
        ("gpt4_fc2", 11544, 512, 2048)]
 reps = int(os.environ.get("REPS", "5"))
