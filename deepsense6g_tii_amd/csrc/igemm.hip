@@ -438,7 +438,10 @@ int run_wgrad(IgemmParams& p, float* dw, int accumulate, float* ws, size_t ws_by
     // >= 4 k-tiles per split
     const int tile = (p.Mg >= 128) ? 1 : 2;
     const long tiles = (long)cdiv(p.Mg, tile == 1 ? 128 : 64) * cdiv(p.Ng, 64);
-    long splits = (1536 + tiles - 1) / tiles;
+    // measured on gfx950 (tools/bench_igemm.py): convs are fastest with ~2048 workgroups in flight, the GPT
+    // linears (large outputs, costlier slab reduction) with ~1024
+    const long target_blocks = (p.R * p.S == 1 && p.H * p.W == 1) ? 1024 : 2048;
+    long splits = (target_blocks + tiles - 1) / tiles;
     const long max_by_k = (p.Kg + 4 * BK - 1) / (4 * BK);
     if (splits > max_by_k) splits = max_by_k;
     const long max_by_ws = (long)(ws_bytes / (out_elems * sizeof(float)));
