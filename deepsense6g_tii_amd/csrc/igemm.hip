@@ -45,6 +45,9 @@ struct IgemmParams {
     int k_per_split;     // multiple of 16
     size_t split_stride; // elements between split-K slabs
     int tiles_n;
+    // DGRAD of a strided conv is run per input-pixel parity class: pixels h = h0 + hstep*hh (hh < Hs), taps
+    // r = r0 + rstep*ri (ri < nr) - only the taps that hit a real output pixel, no structural zeros
+    int h0, hstep, Hs, w0, wstep, Ws, r0, rstep, nr, s0, sstep, ns;
     unsigned a_bytes, b_bytes;  // sizes of the a_src / b_src tensors (buffer descriptors: OOB lanes read zeros)
     int dbg;  // ablation flags (timing experiments only): 1 skip in-loop global loads, 2 skip LDS stores, 4 skip barrier
 };
@@ -141,8 +144,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             a_k[i] = kg;
             const int tap = kg / cin;
             a_c[i] = kg - tap * cin;
-            a_r[i] = tap / p.S;
-            a_s[i] = tap - a_r[i] * p.S;
+            const int nsx = (MODE == MODE_DGRAD) ? p.ns : p.S;
+            a_r[i] = tap / nsx;
+            a_s[i] = tap - a_r[i] * nsx;
             if (MODE == MODE_FWD) {
                 const int ow = mm % p.Wo;
                 const int t = mm / p.Wo;
@@ -152,12 +156,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                 a_x[i] = ow * p.stride - p.pad;
                 a_base[i] = (unsigned)n * (unsigned)(p.H * p.W * p.C);
             } else {
-                const int w_ = mm % p.W;
-                const int t = mm / p.W;
-                const int h_ = t % p.H;
-                const int n = t / p.H;
-                a_y[i] = h_ + p.pad;
-                a_x[i] = w_ + p.pad;
+                const int ww = mm % p.Ws;
+                const int t = mm / p.Ws;
+                const int hh = t % p.Hs;
+                const int n = t / p.Hs;
+                a_y[i] = p.h0 + hh * p.hstep + p.pad;
+                a_x[i] = p.w0 + ww * p.wstep + p.pad;
                 a_base[i] = (unsigned)n * (unsigned)(p.Ho * p.Wo * p.K);
             }
         } else {
@@ -187,8 +191,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             b_ok[i] = (n0 + (idx % (BN / 4)) * 4) < p.Ng;
             const int kg = idx / (BN / 4);
             b_k[i] = kg;
-            b_t[i] = kg / p.K;
-            b_o[i] = kg - b_t[i] * p.K;
+            const int tap = kg / p.K;
+            b_o[i] = kg - tap * p.K;
+            b_t[i] = tap / p.ns;          // running tap row index ri
+            b_n[i] = tap - b_t[i] * p.ns; // running tap column index si
             b_base[i] = (unsigned)(n0 + (idx % (BN / 4)) * 4);
         } else {
             const int ncol = n0 + (idx % (BN / 4)) * 4;
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                 ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
                 off = a_base[i] + (unsigned)((ih * p.W + iw) * p.C + a_c[i]);
             } else if (MODE == MODE_DGRAD) {
-                const int th = a_y[i] - a_r[i], tw = a_x[i] - a_s[i];
+                const int th = a_y[i] - (p.r0 + a_r[i] * p.rstep), tw = a_x[i] - (p.s0 + a_s[i] * p.sstep);
                 int oh = th, ow = tw;
                 bool okk = th >= 0 && tw >= 0;
                 if (p.stride == 2) {
@@ -241,9 +247,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             if (MODE != MODE_WGRAD) {
                 const int cin = (MODE == MODE_FWD) ? p.C : p.K;
                 a_c[i] += BK;
+                const int nsx = (MODE == MODE_DGRAD) ? p.ns : p.S;
                 while (a_c[i] >= cin) {
                     a_c[i] -= cin;
-                    if (++a_s[i] == p.S) { a_s[i] = 0; ++a_r[i]; }
+                    if (++a_s[i] == nsx) { a_s[i] = 0; ++a_r[i]; }
                 }
             }
         }
@@ -254,9 +261,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             if (MODE == MODE_FWD) {
                 off = b_base[i] + (unsigned)b_k[i];
             } else if (MODE == MODE_DGRAD) {
-                off = b_base[i] + (unsigned)((b_o[i] * (p.R * p.S) + b_t[i]) * p.C);
+                const int tap = (p.r0 + b_t[i] * p.rstep) * p.S + p.s0 + b_n[i] * p.sstep;
+                off = b_base[i] + (unsigned)((b_o[i] * (p.R * p.S) + tap) * p.C);
                 b_o[i] += BK;
-                while (b_o[i] >= p.K) { b_o[i] -= p.K; ++b_t[i]; }
+                while (b_o[i] >= p.K) {
+                    b_o[i] -= p.K;
+                    if (++b_n[i] == p.ns) { b_n[i] = 0; ++b_t[i]; }
+                }
             } else {
                 const int ih = b_t[i] * p.stride - p.pad + b_r[i];
                 const int iw = b_o[i] * p.stride - p.pad + b_s[i];
@@ -356,7 +367,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 if (row >= p.Mg) continue;
-                const size_t o = (size_t)row * p.Ng + col;
+                size_t orow = (size_t)row;
+                if (MODE == MODE_DGRAD && p.hstep != 1) {  // parity-class sub-grid -> full-resolution pixel
+                    const int ww = row % p.Ws;
+                    const int t = row / p.Ws;
+                    const int hh = t % p.Hs;
+                    orow = ((size_t)(t / p.Hs) * p.H + p.h0 + hh * p.hstep) * p.W + p.w0 + ww * p.wstep;
+                }
+                const size_t o = orow * p.Ng + col;
                 float v = acc[i][j][r];
                 if (MODE != MODE_WGRAD) {
                     v += bias;
@@ -471,6 +489,8 @@ void fill_conv(IgemmParams& p, int N, int H, int W, int C, int K, int R, int S, 
     p.Ho = (H + 2 * pad - R) / stride + 1;
     p.Wo = (W + 2 * pad - S) / stride + 1;
     p.drop_scale = 1.f;
+    p.h0 = 0; p.hstep = 1; p.Hs = H; p.w0 = 0; p.wstep = 1; p.Ws = W;
+    p.r0 = 0; p.rstep = 1; p.nr = R; p.s0 = 0; p.sstep = 1; p.ns = S;
 }
 
 // byte sizes of the three tensors of a conv (for the buffer descriptors); all must stay below the OOB sentinel
@@ -515,6 +535,22 @@ int ds6g_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
     const ConvBytes cb = conv_bytes(p);
     DS6G_CHECK_ARG(cb.ok);
     p.a_bytes = (unsigned)cb.y; p.b_bytes = (unsigned)cb.w;
+    if (stride == 2 && H % 2 == 0 && W % 2 == 0) {
+        // four input-pixel parity classes; class (ph,pw) only sees taps r = (ph+pad) mod 2 (+2..), s likewise
+        for (int ph = 0; ph < 2; ++ph)
+            for (int pw = 0; pw < 2; ++pw) {
+                IgemmParams q = p;
+                q.h0 = ph; q.hstep = 2; q.Hs = H / 2; q.w0 = pw; q.wstep = 2; q.Ws = W / 2;
+                q.r0 = (ph + pad) & 1; q.rstep = 2; q.nr = q.r0 < R ? (R - q.r0 + 1) / 2 : 0;
+                q.s0 = (pw + pad) & 1; q.sstep = 2; q.ns = q.s0 < S ? (S - q.s0 + 1) / 2 : 0;
+                q.Mg = N * q.Hs * q.Ws; q.Ng = C; q.Kg = q.nr * q.ns * K;
+                if (q.ns == 0) q.ns = 1;  // Kg == 0: the launch only zero-fills (or keeps, when accumulating) its pixels
+                if (q.Kg == 0 && accumulate) continue;
+                int rc = launch_igemm<MODE_DGRAD>(q, (hipStream_t)stream);
+                if (rc) return rc;
+            }
+        return DS6G_OK;
+    }
     p.Mg = N * H * W; p.Ng = C; p.Kg = R * S * K;
     return launch_igemm<MODE_DGRAD>(p, (hipStream_t)stream);
 }

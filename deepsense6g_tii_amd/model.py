@@ -594,10 +594,14 @@ class TransFuser(nn.Module):
         if blk.downsample is not None:
             dcd, _ = self._bn_bwd(blk.downsample[1], dres, None, cd, sd)
             self._wgrad_conv(blk.downsample[0], x, dcd, 1, blk.stride, 0)
-            dx = ops.conv2d_dgrad(dcd, self._w(blk.downsample[0].weight), tuple(x.shape), 1, 1, blk.stride, 0)
+            # the 3x3 dgrad writes every input pixel; the strided 1x1 only touches the even/even parity class
+            dx = ops.conv2d_dgrad(dc1, self._w(blk.conv1.weight), tuple(x.shape), 3, 3, blk.stride, 1)
+            ops.conv2d_dgrad(dcd, self._w(blk.downsample[0].weight), tuple(x.shape), 1, 1, blk.stride, 0, out=dx,
+                             accumulate=True)
         else:
             dx = dres
-        ops.conv2d_dgrad(dc1, self._w(blk.conv1.weight), tuple(x.shape), 3, 3, blk.stride, 1, out=dx, accumulate=True)
+            ops.conv2d_dgrad(dc1, self._w(blk.conv1.weight), tuple(x.shape), 3, 3, blk.stride, 1, out=dx,
+                             accumulate=True)
         return dx
 
     def _gpt_block_bwd(self, blk, ctx, dx2, B, T):
