@@ -9,9 +9,14 @@
 // That is exactly the B-operand shape (B[k = half][j = q]) of the next product
 // O^T += V^T P^T when MFMA step r pairs the two keys {kA(r), kA(r)+4}: P never moves between
 // lanes or through LDS, and the per-query softmax state (m, l) lives on the lane of its query.
-// K/V tiles (32 keys) are staged in LDS row-major with an odd row stride (HD+1): both the
-// "key on the lane" read (stride HD+1, odd -> conflict-free) and the "dim on the lane" read
-// (consecutive floats) are conflict-free ds_read_b32 from the same image.
+//
+// Tiles (32 rows x HD) of K/V (or Q/dO in the dK/dV kernel) go global -> LDS by buffer_load...lds DMA, one tile
+// ahead, two buffers; the image is [row][HD] with the 16-B chunk index XOR-swizzled by the row, which makes both
+// access shapes conflict-free: "row on the lane" (ds_read_b128: 4 reduction steps per read, the reduction order
+// over the head dim is permuted so a lane half owns a contiguous half of it) and "dim on the lane" (ds_read_b32).
+// Workgroup = 4 waves = 128 queries (K/V tile reuse 4x).  The key loop (query loop for dK/dV) can be SPLIT
+// across workgroups so the grid fills the 256 CUs evenly at any batch size; partial results are merged by a
+// small second kernel (flash-decoding style for the forward: rescale by exp(m_s - m)).  Deterministic: no atomics.
 #include "common.h"
 
 namespace {
@@ -20,15 +25,19 @@ struct AttnParams {
     const float* q;
     const float* k;
     const float* v;
-    float* o;            // fwd: output; bwd: forward output (read)
+    float* o;            // fwd: output (or partial slabs); bwd: forward output (read)
     float* lse;          // [B][nh][T]
+    float* ml;           // fwd split: [S][B][nh][T][2] running max / partial sum
     const float* d_o;    // bwd
     float* delta;        // [B][nh][T]  rowsum(dO * O)
     float* dq;
     float* dk;
     float* dv;
-    int T, nh;
+    int T, nh, B;
     int ld;              // row stride (floats) of q/k/v/o/do/dq/dk/dv
+    int splits, tiles_per_split;
+    size_t slab;         // floats between split slabs of o / dq / dk / dv
+    unsigned bytes;      // size of each [B*T][ld] tensor
     float scale;
     uint32_t thr;
     float dscale;
@@ -38,37 +47,113 @@ struct AttnParams {
 
 __device__ __forceinline__ int krow16(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-template <int HD, int NTHR>
-struct TileRegs {
-    static constexpr int CNT = (8 * HD + NTHR - 1) / NTHR;  // float4 per thread for a 32 x HD tile
-    f32x4 v[CNT];
-};
+// XOR applied to the 16-B chunk index of row r (NC = HD/4 chunks per row)
+template <int HD>
+__device__ __forceinline__ int swz(int r) {
+    constexpr int NC = HD / 4;
+    if (NC >= 16) return r & 15;
+    if (NC == 8) return (r >> 1) & 7;
+    return (r >> 2) & 3;
+}
 
-// global [32 rows][HD] (rows row0.., zero beyond T) -> registers
-template <int HD, int NTHR>
-__device__ __forceinline__ void tile_load(TileRegs<HD, NTHR>& t, const float* base, int ld, int row0, int T, int tid) {
+// DMA one 32 x HD tile (rows row0.. of the [B*T][ld] tensor behind srd, zero beyond T) into lds_tile
+template <int HD>
+__device__ __forceinline__ void tile_dma(const i32x4 srd, const float* lds_tile, unsigned base_off, int row0, int T,
+                                         int ld, int wave, int lane) {
+    constexpr int NC = HD / 4;
+    constexpr int NWI = HD / 8;  // wave-instructions (64 chunks) per tile
 #pragma unroll
-    for (int i = 0; i < TileRegs<HD, NTHR>::CNT; ++i) {
-        const int idx = tid + i * NTHR;
-        const int row = idx / (HD / 4);
-        const int c4 = (idx % (HD / 4)) * 4;
-        const bool ok = idx < 8 * HD && (row0 + row) < T;
-        t.v[i] = ok ? *reinterpret_cast<const f32x4*>(base + (long)(row0 + row) * ld + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < (NWI + 3) / 4; ++j) {
+        const int wi = wave + 4 * j;
+        if (wi < NWI) {
+            const int g = wi * 64 + lane;
+            const int row = g / NC, pos = g % NC;
+            const int c = pos ^ swz<HD>(row);
+            const unsigned off = base_off + (unsigned)(row0 + row) * (unsigned)ld + (unsigned)(c * 4);
+            dma16(srd, lds_addr(lds_tile) + (unsigned)wi * 1024u, (row0 + row) < T ? off * 4u : OOB_OFF);
+        }
     }
 }
 
-template <int HD, int NTHR>
-__device__ __forceinline__ void tile_store(const TileRegs<HD, NTHR>& t, float* lds, int tid) {
+// Tiles are addressed by their LDS BYTE address, laundered once per loop step through an empty asm: the swizzled
+// per-lane addresses are loop-invariant, and hipcc would otherwise hoist ~250 of them out of the tile loop into
+// VGPRs (spilling the dK/dV kernel).  Recomputing them next to each read is free under the 64-cycle MFMAs.
+typedef __attribute__((address_space(3))) const float lds_cf;
+typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+__device__ __forceinline__ unsigned opaque_tile(const float* tile) {
+    unsigned a = lds_addr(tile);
+    asm volatile("" : "+v"(a));
+    return a;
+}
+// "row on the lane": 4 consecutive reduction elements (chunk c) of row r
+template <int HD>
+__device__ __forceinline__ f32x4 row_read(unsigned tile, int r, int c) {
+    return *reinterpret_cast<lds_cf4*>(tile + (unsigned)(r * HD * 4 + ((c ^ swz<HD>(r)) << 4)));
+}
+// "dim on the lane": element d = 32*blk + (lane&31) of row krow16(r, half).  The swizzled address splits into a
+// lane part that takes only 8 distinct values (dtab, built once per kernel) and a compile-time part that folds
+// into the ds_read offset field:   row = cr + 4*half with bit 2 of cr clear, so the row XOR is (const) ^ (half term).
+template <int HD>
+__device__ __forceinline__ void make_dtab(unsigned* dtab, int l31, int half) {
+    constexpr int NC = HD / 4;
+    const int dc = (HD < 32 && l31 >= HD) ? HD - 1 : l31;  // HD = 16: lanes 16..31 re-read a valid element (unused rows)
+    const int hx = NC >= 16 ? 4 * half : (NC == 8 ? 2 * half : half);
 #pragma unroll
-    for (int i = 0; i < TileRegs<HD, NTHR>::CNT; ++i) {
-        const int idx = tid + i * NTHR;
-        if (idx < 8 * HD) {
-            const int row = idx / (HD / 4);
-            const int c4 = (idx % (HD / 4)) * 4;
-            float* d = lds + row * (HD + 1) + c4;
-            d[0] = t.v[i][0]; d[1] = t.v[i][1]; d[2] = t.v[i][2]; d[3] = t.v[i][3];
-        }
+    for (int k = 0; k < 8; ++k)
+        dtab[k] = (unsigned)(4 * half * HD * 4 + ((((dc >> 2) ^ hx ^ k) & (NC - 1)) << 4) + (dc & 3) * 4);
+}
+template <int HD>
+__device__ __forceinline__ float dim_read(unsigned tile, const unsigned* dtab, int r, int blk) {
+    constexpr int NC = HD / 4;
+    const int cr = krow16(r, 0);
+    const int k = NC >= 16 ? (cr & 7) : (NC == 8 ? ((cr >> 1) & 7) : ((cr >> 2) & 3));
+    const int cst = cr * HD * 4 + (NC >= 16 ? 128 * (blk ^ ((cr >> 3) & 1)) : 0);
+    return *reinterpret_cast<lds_cf*>(tile + dtab[k] + (unsigned)cst);
+}
+
+// per-lane operand fragment of row `row` for the transposed products: element ss <-> dim half*HD/2 + ss
+template <int HD>
+__device__ __forceinline__ void load_frag(float* reg, const float* base, long row_off, int half, float mul) {
+#pragma unroll
+    for (int j = 0; j < HD / 8; ++j) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + row_off + half * (HD / 2) + 4 * j);
+        reg[4 * j] = v[0] * mul; reg[4 * j + 1] = v[1] * mul; reg[4 * j + 2] = v[2] * mul; reg[4 * j + 3] = v[3] * mul;
     }
+}
+
+// acc += A . B^T over the head dim: A rows come from the LDS tile (row = lane&31), B from registers
+template <int HD>
+__device__ __forceinline__ void mma_rows(f32x16& acc, unsigned tile, const float* breg, int l31, int half) {
+    constexpr int NCH = HD / 8;  // 16-B chunks per lane half
+    f32x4 cur = row_read<HD>(tile, l31, half * NCH);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const f32x4 nxt = row_read<HD>(tile, l31, half * NCH + (j + 1 < NCH ? j + 1 : j));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[e], breg[4 * j + e], acc, 0, 0, 0);
+        cur = nxt;
+    }
+}
+
+// acc[blk] (X^T[d][col-on-lane]) += sum_r tile[krow16(r,half)][d] * p[r]
+template <int HD>
+__device__ __forceinline__ void mma_dims(f32x16* acc, unsigned tile, const f32x16& p, const unsigned* dtab) {
+    constexpr int NB = (HD + 31) / 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+            acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(dim_read<HD>(tile, dtab, r, blk), p[r], acc[blk], 0, 0, 0);
+    }
+    // pin the schedule: LDS reads run exactly one r-step ahead of the MFMAs that consume them (left alone the
+    // scheduler issues all 16*NB reads first and keeps 16*NB values + addresses live)
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * NB, 0);
+#pragma unroll
+    for (int r = 0; r < 14; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NB, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NB, 0);
 }
 
 // write an accumulator set acc[blk][16] = X^T[d][row] to global X[row][d] (row on the lane)
@@ -90,57 +175,52 @@ __device__ __forceinline__ void store_rows(const f32x16* acc, float* base, int l
     }
 }
 
+#define ATTN_COMMON()                                                                                  \
+    constexpr int NB = (HD + 31) / 32;                                                                 \
+    __shared__ __attribute__((aligned(16))) float Xa0[32 * HD];                                        \
+    __shared__ __attribute__((aligned(16))) float Xa1[32 * HD];                                        \
+    __shared__ __attribute__((aligned(16))) float Xb0[32 * HD];                                        \
+    __shared__ __attribute__((aligned(16))) float Xb1[32 * HD];                                        \
+    const int tid = threadIdx.x, lane = tid & 63;                                                      \
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                         \
+    const int l31 = lane & 31, half = lane >> 5;                                                       \
+    const int h = blockIdx.y % p.nh, split = blockIdx.y / p.nh, b = blockIdx.z;                        \
+    const int T = p.T;                                                                                 \
+    const long head_off = (long)b * T * p.ld + h * HD;                                                 \
+    const int ntiles = (T + 31) / 32;                                                                  \
+    const int t_begin = split * p.tiles_per_split;                                                     \
+    const int t_end = min(ntiles, t_begin + p.tiles_per_split);                                        \
+    unsigned dtab[8];                                                                                  \
+    make_dtab<HD>(dtab, l31, half);                                                                    \
+    (void)NB;
+
 // ------------------------------------------------------------------------------------------------
-template <int HD, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
-    constexpr int NTHR = NW * 64;
-    constexpr int LDS_LD = HD + 1;
-    constexpr int NB = (HD + 31) / 32;
-    __shared__ float Ks[32 * LDS_LD];
-    __shared__ float Vs[32 * LDS_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int T = p.T;
-    const int q_row = blockIdx.x * (32 * NW) + wave * 32 + l31;
-    const long head_off = (long)b * T * p.ld + h * HD;
-    const float* qb = p.q + head_off;
-    const float* kb = p.k + head_off;
-    const float* vb = p.v + head_off;
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
+    ATTN_COMMON();
+    const int q_row = blockIdx.x * 128 + wave * 32 + l31;
+    const i32x4 k_srd = make_srd(p.k, p.bytes), v_srd = make_srd(p.v, p.bytes);
 
     float qreg[HD / 2];
-    {
-        const int qr = q_row < T ? q_row : T - 1;
-#pragma unroll
-        for (int ss = 0; ss < HD / 2; ++ss) qreg[ss] = qb[(long)qr * p.ld + 2 * ss + half] * p.scale;
-    }
+    load_frag<HD>(qreg, p.q, head_off + (long)(q_row < T ? q_row : T - 1) * p.ld, half, p.scale);
     f32x16 oacc[NB];
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[blk][r] = 0.f;
     float m = -INFINITY, l = 0.f;
-
-    const int ntiles = (T + 31) / 32;
-    TileRegs<HD, NTHR> kr, vr;
-    tile_load<HD, NTHR>(kr, kb, p.ld, 0, T, tid);
-    tile_load<HD, NTHR>(vr, vb, p.ld, 0, T, tid);
     const long drop_row = ((long)(b * p.nh + h) * T + q_row) * T;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();
-        tile_store<HD, NTHR>(kr, Ks, tid);
-        tile_store<HD, NTHR>(vr, Vs, tid);
-        __syncthreads();
-        if (kt + 1 < ntiles) {
-            tile_load<HD, NTHR>(kr, kb, p.ld, (kt + 1) * 32, T, tid);
-            tile_load<HD, NTHR>(vr, vb, p.ld, (kt + 1) * 32, T, tid);
+
+    auto step = [&](const float* Kcp, const float* Vcp, const float* Kn, const float* Vn, int kt, bool more) {
+        if (more) {
+            tile_dma<HD>(k_srd, Kn, (unsigned)head_off, (kt + 1) * 32, T, p.ld, wave, lane);
+            tile_dma<HD>(v_srd, Vn, (unsigned)head_off, (kt + 1) * 32, T, p.ld, wave, lane);
         }
+        const unsigned Kc = opaque_tile(Kcp), Vc = opaque_tile(Vcp);
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-        for (int ss = 0; ss < HD / 2; ++ss)
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[l31 * LDS_LD + 2 * ss + half], qreg[ss], s, 0, 0, 0);
+        mma_rows<HD>(s, Kc, qreg, l31, half);
         const int key0 = kt * 32;
         float mloc = -INFINITY;
 #pragma unroll
@@ -170,85 +250,109 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
                 s[r] = ds6g_keep(p.seed, p.seed_off + (uint64_t)(drop_row + key), p.thr) ? s[r] * p.dscale : 0.f;
             }
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float* vrow = Vs + krow16(r, half) * LDS_LD;
-#pragma unroll
-            for (int blk = 0; blk < NB; ++blk) {
-                const int d = blk * 32 + l31;
-                oacc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[d < HD ? d : HD - 1], s[r], oacc[blk], 0, 0, 0);
-            }
-        }
+        mma_dims<HD>(oacc, Vc, s, dtab);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    if (t_begin < t_end) {
+        tile_dma<HD>(k_srd, Xa0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
+        tile_dma<HD>(v_srd, Xb0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = t_begin; kt < t_end; kt += 2) {
+        step(Xa0, Xb0, Xa1, Xb1, kt, kt + 1 < t_end);
+        if (kt + 1 < t_end) step(Xa1, Xb1, Xa0, Xb0, kt + 1, kt + 2 < t_end);
     }
     const float ltot = l + __shfl_xor(l, 32, 64);
-    store_rows<HD>(oacc, p.o + head_off, p.ld, q_row, T, half, 1.0f / ltot);
-    if (half == 0 && q_row < T) p.lse[(long)(b * p.nh + h) * T + q_row] = m + __logf(ltot);
+    const long stat = (long)(b * p.nh + h) * T + q_row;
+    if (p.splits == 1) {
+        store_rows<HD>(oacc, p.o + head_off, p.ld, q_row, T, half, 1.0f / ltot);
+        if (half == 0 && q_row < T) p.lse[stat] = m + __logf(ltot);
+    } else {
+        store_rows<HD>(oacc, p.o + (size_t)split * p.slab + head_off, p.ld, q_row, T, half, 1.0f);
+        if (half == 0 && q_row < T) {
+            float* mlp = p.ml + ((size_t)split * p.B * p.nh * T + stat) * 2;
+            mlp[0] = m;
+            mlp[1] = ltot;
+        }
+    }
+}
+
+// o = sum_s o_s exp(m_s - m) / sum_s l_s exp(m_s - m); lse = m + log(...)
+__global__ __launch_bounds__(256) void attn_fwd_merge_kernel(const float* __restrict__ part, const float* __restrict__ ml,
+                                                             float* __restrict__ o, float* __restrict__ lse, int B, int T,
+                                                             int nh, int hd, int ld, int splits, size_t slab) {
+    const int c4n = nh * hd / 4;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * T * c4n) return;
+    const int c4 = (int)(i % c4n);
+    const long row = i / c4n;  // b*T + t
+    const int h = (c4 * 4) / hd;
+    const int b = (int)(row / T), t = (int)(row % T);
+    const size_t stat = ((size_t)(b * nh + h) * T + t);
+    const size_t sstride = (size_t)B * nh * T;
+    float m = -INFINITY;
+    for (int s = 0; s < splits; ++s) m = fmaxf(m, ml[(s * sstride + stat) * 2]);
+    float l = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s) {
+        const float ms = ml[(s * sstride + stat) * 2];
+        const float w = ms == -INFINITY ? 0.f : __expf(ms - m);
+        l += ml[(s * sstride + stat) * 2 + 1] * w;
+        acc += w * *reinterpret_cast<const f32x4*>(part + (size_t)s * slab + row * ld + c4 * 4);
+    }
+    *reinterpret_cast<f32x4*>(o + row * ld + c4 * 4) = acc * (1.0f / l);
+    if ((c4 * 4) % hd == 0) lse[stat] = m + __logf(l);
 }
 
 // ------------------------------------------------------------------------------------------------
-// dQ (and delta) : one wave = 32 queries, loop over key tiles
-template <int HD, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams p) {
-    constexpr int NTHR = NW * 64;
-    constexpr int LDS_LD = HD + 1;
-    constexpr int NB = (HD + 31) / 32;
-    __shared__ float Ks[32 * LDS_LD];
-    __shared__ float Vs[32 * LDS_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int T = p.T;
-    const int q_row = blockIdx.x * (32 * NW) + wave * 32 + l31;
+// dQ (and delta): one wave = 32 queries, loop over (a split of) the key tiles
+template <int HD>
+__global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(const AttnParams p) {
+    ATTN_COMMON();
+    const int q_row = blockIdx.x * 128 + wave * 32 + l31;
     const bool q_ok = q_row < T;
-    const long head_off = (long)b * T * p.ld + h * HD;
-    const float* kb = p.k + head_off;
-    const float* vb = p.v + head_off;
+    const i32x4 k_srd = make_srd(p.k, p.bytes), v_srd = make_srd(p.v, p.bytes);
 
     float qreg[HD / 2], doreg[HD / 2];
     float delta = 0.f;
     {
         const long ro = head_off + (long)(q_ok ? q_row : T - 1) * p.ld;
+        load_frag<HD>(qreg, p.q, ro, half, p.scale);
+        load_frag<HD>(doreg, p.d_o, ro, half, q_ok ? 1.f : 0.f);
 #pragma unroll
-        for (int ss = 0; ss < HD / 2; ++ss) {
-            const int d = 2 * ss + half;
-            qreg[ss] = p.q[ro + d] * p.scale;
-            doreg[ss] = q_ok ? p.d_o[ro + d] : 0.f;
-            delta += doreg[ss] * p.o[ro + d];
+        for (int j = 0; j < HD / 8; ++j) {
+            const f32x4 ov = *reinterpret_cast<const f32x4*>(p.o + ro + half * (HD / 2) + 4 * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) delta += doreg[4 * j + e] * ov[e];
         }
         delta += __shfl_xor(delta, 32, 64);
     }
     const long stat_idx = (long)(b * p.nh + h) * T + q_row;
     const float lse = q_ok ? p.lse[stat_idx] : INFINITY;
-    if (half == 0 && q_ok) p.delta[stat_idx] = delta;
+    if (half == 0 && q_ok && split == 0) p.delta[stat_idx] = delta;
 
     f32x16 dq[NB];
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[blk][r] = 0.f;
-
-    const int ntiles = (T + 31) / 32;
-    TileRegs<HD, NTHR> kr, vr;
-    tile_load<HD, NTHR>(kr, kb, p.ld, 0, T, tid);
-    tile_load<HD, NTHR>(vr, vb, p.ld, 0, T, tid);
     const long drop_row = ((long)(b * p.nh + h) * T + q_row) * T;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();
-        tile_store<HD, NTHR>(kr, Ks, tid);
-        tile_store<HD, NTHR>(vr, Vs, tid);
-        __syncthreads();
-        if (kt + 1 < ntiles) {
-            tile_load<HD, NTHR>(kr, kb, p.ld, (kt + 1) * 32, T, tid);
-            tile_load<HD, NTHR>(vr, vb, p.ld, (kt + 1) * 32, T, tid);
+
+    auto step = [&](const float* Kcp, const float* Vcp, const float* Kn, const float* Vn, int kt, bool more) {
+        if (more) {
+            tile_dma<HD>(k_srd, Kn, (unsigned)head_off, (kt + 1) * 32, T, p.ld, wave, lane);
+            tile_dma<HD>(v_srd, Vn, (unsigned)head_off, (kt + 1) * 32, T, p.ld, wave, lane);
         }
+        const unsigned Kc = opaque_tile(Kcp), Vc = opaque_tile(Vcp);
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-        for (int ss = 0; ss < HD / 2; ++ss) {
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[l31 * LDS_LD + 2 * ss + half], qreg[ss], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[l31 * LDS_LD + 2 * ss + half], doreg[ss], dp, 0, 0, 0);
-        }
+        mma_rows<HD>(s, Kc, qreg, l31, half);
+        mma_rows<HD>(dp, Vc, doreg, l31, half);
         const int key0 = kt * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -258,187 +362,267 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams p
             if (p.thr) g = ds6g_keep(p.seed, p.seed_off + (uint64_t)(drop_row + key), p.thr) ? g * p.dscale : 0.f;
             s[r] = pr * (g - delta) * p.scale;  // dS (scaled)
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float* krow = Ks + krow16(r, half) * LDS_LD;
-#pragma unroll
-            for (int blk = 0; blk < NB; ++blk) {
-                const int d = blk * 32 + l31;
-                dq[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[d < HD ? d : HD - 1], s[r], dq[blk], 0, 0, 0);
-            }
-        }
+        mma_dims<HD>(dq, Kc, s, dtab);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    if (t_begin < t_end) {
+        tile_dma<HD>(k_srd, Xa0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
+        tile_dma<HD>(v_srd, Xb0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
     }
-    store_rows<HD>(dq, p.dq + head_off, p.ld, q_row, T, half, 1.0f);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = t_begin; kt < t_end; kt += 2) {
+        step(Xa0, Xb0, Xa1, Xb1, kt, kt + 1 < t_end);
+        if (kt + 1 < t_end) step(Xa1, Xb1, Xa0, Xb0, kt + 1, kt + 2 < t_end);
+    }
+    store_rows<HD>(dq, p.dq + (size_t)split * p.slab + head_off, p.ld, q_row, T, half, 1.0f);
 }
 
-// dK, dV : one wave = 32 keys (key on the lane), loop over query tiles
-template <int HD, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams p) {
-    constexpr int NTHR = NW * 64;
-    constexpr int LDS_LD = HD + 1;
-    constexpr int NB = (HD + 31) / 32;
-    __shared__ float Qs[32 * LDS_LD];
-    __shared__ float Os[32 * LDS_LD];  // dO tile
-    __shared__ float lse_s[32];
-    __shared__ float delta_s[32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int T = p.T;
-    const int key = blockIdx.x * (32 * NW) + wave * 32 + l31;
+// dK, dV: one wave = 32 keys (key on the lane), loop over (a split of) the query tiles.
+// PART 0 = both (4 products per tile); 1 = dV only (S, dV); 2 = dK only (S, dP, dK).  At HD = 128 the fused form
+// needs > 512 registers (K, V fragments + two accumulator sets), so it runs as PART 1 + PART 2.
+template <int HD, int PART>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
+    constexpr bool DO_DV = PART != 2, DO_DK = PART != 1;
+    ATTN_COMMON();
+    __shared__ float lse_s[2][32];
+    __shared__ float delta_s[2][32];
+    const int key = blockIdx.x * 128 + wave * 32 + l31;
     const bool key_ok = key < T;
-    const long head_off = (long)b * T * p.ld + h * HD;
-    const float* qb = p.q + head_off;
-    const float* dob = p.d_o + head_off;
+    const i32x4 q_srd = make_srd(p.q, p.bytes), do_srd = make_srd(p.d_o, p.bytes);
 
     float kreg[HD / 2], vreg[HD / 2];
     {
         const long ro = head_off + (long)(key_ok ? key : T - 1) * p.ld;
-#pragma unroll
-        for (int ss = 0; ss < HD / 2; ++ss) {
-            kreg[ss] = p.k[ro + 2 * ss + half];
-            vreg[ss] = p.v[ro + 2 * ss + half];
-        }
+        load_frag<HD>(kreg, p.k, ro, half, 1.f);
+        if (DO_DK) load_frag<HD>(vreg, p.v, ro, half, 1.f);
     }
     f32x16 dk[NB], dv[NB];
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[blk][r] = 0.f; dv[blk][r] = 0.f; }
-
-    const int ntiles = (T + 31) / 32;
     const long stat_base = (long)(b * p.nh + h) * T;
-    TileRegs<HD, NTHR> qr, dr;
-    tile_load<HD, NTHR>(qr, qb, p.ld, 0, T, tid);
-    tile_load<HD, NTHR>(dr, dob, p.ld, 0, T, tid);
-    float lse_r = 0.f, delta_r = 0.f;
-    if (tid < 32) {
-        lse_r = tid < T ? p.lse[stat_base + tid] : INFINITY;
-        delta_r = tid < T ? p.delta[stat_base + tid] : 0.f;
-    }
-    for (int qt = 0; qt < ntiles; ++qt) {
-        __syncthreads();
-        tile_store<HD, NTHR>(qr, Qs, tid);
-        tile_store<HD, NTHR>(dr, Os, tid);
-        if (tid < 32) { lse_s[tid] = lse_r; delta_s[tid] = delta_r; }
-        __syncthreads();
-        if (qt + 1 < ntiles) {
-            tile_load<HD, NTHR>(qr, qb, p.ld, (qt + 1) * 32, T, tid);
-            tile_load<HD, NTHR>(dr, dob, p.ld, (qt + 1) * 32, T, tid);
-            if (tid < 32) {
-                const int qn = (qt + 1) * 32 + tid;
-                lse_r = qn < T ? p.lse[stat_base + qn] : INFINITY;
-                delta_r = qn < T ? p.delta[stat_base + qn] : 0.f;
-            }
+
+    auto stats = [&](int qt, int buf) {  // per-query lse / delta of tile qt -> LDS (first 32 threads)
+        if (tid < 32) {
+            const int qn = qt * 32 + tid;
+            lse_s[buf][tid] = qn < T ? p.lse[stat_base + qn] : INFINITY;
+            delta_s[buf][tid] = qn < T ? p.delta[stat_base + qn] : 0.f;
         }
+    };
+    auto step = [&](const float* Qcp, const float* Ocp, const float* Qn, const float* On, int qt, int buf, bool more) {
+        if (more) {
+            tile_dma<HD>(q_srd, Qn, (unsigned)head_off, (qt + 1) * 32, T, p.ld, wave, lane);
+            tile_dma<HD>(do_srd, On, (unsigned)head_off, (qt + 1) * 32, T, p.ld, wave, lane);
+            stats(qt + 1, buf ^ 1);
+        }
+        const unsigned Qc = opaque_tile(Qcp), Oc = opaque_tile(Ocp);
         // S[q][key], dP[q][key]: query rows in registers, key on the lane
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-        for (int ss = 0; ss < HD / 2; ++ss) {
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[l31 * LDS_LD + 2 * ss + half], kreg[ss], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[l31 * LDS_LD + 2 * ss + half], vreg[ss], dp, 0, 0, 0);
-        }
+        mma_rows<HD>(s, Qc, kreg, l31, half);
+        __builtin_amdgcn_sched_barrier(0);
+        if (DO_DK) mma_rows<HD>(dp, Oc, vreg, l31, half);
+        __builtin_amdgcn_sched_barrier(0);
         const int q0 = qt * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ql = krow16(r, half);
-            const int qg = q0 + ql;
-            float pr = __expf(s[r] * p.scale - lse_s[ql]);  // lse = +inf for q >= T -> 0
+            float pr = __expf(s[r] * p.scale - lse_s[buf][ql]);  // lse = +inf for q >= T -> 0
             float g = dp[r];
             if (p.thr) {
-                const bool keep = ds6g_keep(p.seed, p.seed_off + (uint64_t)((stat_base + qg) * (long)T + key), p.thr);
+                const bool keep = ds6g_keep(p.seed, p.seed_off + (uint64_t)((stat_base + q0 + ql) * (long)T + key), p.thr);
                 g = keep ? g * p.dscale : 0.f;
-                dp[r] = pr * (g - delta_s[ql]) * p.scale;
+                dp[r] = pr * (g - delta_s[buf][ql]) * p.scale;
                 pr = keep ? pr * p.dscale : 0.f;
             } else {
-                dp[r] = pr * (g - delta_s[ql]) * p.scale;
+                dp[r] = pr * (g - delta_s[buf][ql]) * p.scale;
             }
             s[r] = pr;  // dropped probabilities
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float* orow = Os + krow16(r, half) * LDS_LD;
-            const float* qrow = Qs + krow16(r, half) * LDS_LD;
-#pragma unroll
-            for (int blk = 0; blk < NB; ++blk) {
-                const int d = blk * 32 + l31;
-                const int dc = d < HD ? d : HD - 1;
-                dv[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(orow[dc], s[r], dv[blk], 0, 0, 0);
-                dk[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[dc], dp[r], dk[blk], 0, 0, 0);
-            }
-        }
+        __builtin_amdgcn_sched_barrier(0);  // phase fences keep the LDS-read prefetch of one product from
+        if (DO_DV) mma_dims<HD>(dv, Oc, s, dtab);  // overlapping the live registers of the next
+        __builtin_amdgcn_sched_barrier(0);
+        if (DO_DK) mma_dims<HD>(dk, Qc, dp, dtab);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    if (t_begin < t_end) {
+        tile_dma<HD>(q_srd, Xa0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
+        tile_dma<HD>(do_srd, Xb0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
+        stats(t_begin, 0);
     }
-    store_rows<HD>(dk, p.dk + head_off, p.ld, key, T, half, 1.0f);
-    store_rows<HD>(dv, p.dv + head_off, p.ld, key, T, half, 1.0f);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int qt = t_begin; qt < t_end; qt += 2) {
+        step(Xa0, Xb0, Xa1, Xb1, qt, 0, qt + 1 < t_end);
+        if (qt + 1 < t_end) step(Xa1, Xb1, Xa0, Xb0, qt + 1, 1, qt + 2 < t_end);
+    }
+    if (DO_DK) store_rows<HD>(dk, p.dk + (size_t)split * p.slab + head_off, p.ld, key, T, half, 1.0f);
+    if (DO_DV) store_rows<HD>(dv, p.dv + (size_t)split * p.slab + head_off, p.ld, key, T, half, 1.0f);
 }
 
-template <int KIND, int HD>
-int launch_attn(const AttnParams& p, int B, hipStream_t st) {
-    // 64-query (2-wave) blocks when 128-query blocks would leave the 256 CUs under-filled
-    const long blocks4 = (long)cdiv(p.T, 128) * p.nh * B;
-    // the 2-wave dK/dV kernel at HD=128 would spill (K,V fragments + two accumulator sets)
-    const bool four = blocks4 >= 512 || (KIND == 2 && HD == 128);
-    if (four) {
-        dim3 grid(cdiv(p.T, 128), p.nh, B), block(256);
-        if (KIND == 0) hipLaunchKernelGGL((attn_fwd_kernel<HD, 4>), grid, block, 0, st, p);
-        if (KIND == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 4>), grid, block, 0, st, p);
-        if (KIND == 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4>), grid, block, 0, st, p);
-    } else {
-        dim3 grid(cdiv(p.T, 64), p.nh, B), block(128);
-        if (KIND == 0) hipLaunchKernelGGL((attn_fwd_kernel<HD, 2>), grid, block, 0, st, p);
-        if (KIND == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 2>), grid, block, 0, st, p);
-        if (KIND == 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 2>), grid, block, 0, st, p);
+// out = sum_s part[s]   (dq / dk / dv split slabs)
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ part, float* __restrict__ out, long n4,
+                                                       int splits, size_t slab) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 s = *reinterpret_cast<const f32x4*>(part + i * 4);
+    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(part + (size_t)k * slab + i * 4);
+    *reinterpret_cast<f32x4*>(out + i * 4) = s;
+}
+
+// number of loop splits: fills the chip evenly.  cap = workgroups resident at once (256 CUs x per-CU residency)
+int pick_splits(long base_blocks, int ntiles, int per_cu, int max_splits) {
+    const long cap = 256L * per_cu;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= max_splits && s <= ntiles; ++s) {
+        const int tps = cdiv(ntiles, s);
+        const int eff = cdiv(ntiles, tps);  // splits actually used
+        const long rounds = cdiv(base_blocks * eff, cap);
+        const double cost = (double)rounds * tps + 0.35 * eff;  // loop trips per CU slot + a merge/prologue penalty
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
     }
-    DS6G_LAUNCH_CHECK();
-    return DS6G_OK;
+    return best;
 }
 
 template <int KIND>
-int dispatch_hd(const AttnParams& p, int B, int hd, hipStream_t st) {
+int launch_hd(const AttnParams& p, int hd, dim3 grid, hipStream_t st) {
+#define ATTN_CASE(HDV)                                                                                        \
+    case HDV:                                                                                                 \
+        if (KIND == 0) hipLaunchKernelGGL((attn_fwd_kernel<HDV>), grid, dim3(256), 0, st, p);                 \
+        if (KIND == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<HDV>), grid, dim3(256), 0, st, p);              \
+        if (KIND == 2) {                                                                                      \
+            if (HDV >= 128) {                                                                                 \
+                hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 1>), grid, dim3(256), 0, st, p);                 \
+                hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 2>), grid, dim3(256), 0, st, p);                 \
+            } else {                                                                                          \
+                hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 0>), grid, dim3(256), 0, st, p);                 \
+            }                                                                                                 \
+        }                                                                                                     \
+        break;
     switch (hd) {
-        case 16: return launch_attn<KIND, 16>(p, B, st);
-        case 32: return launch_attn<KIND, 32>(p, B, st);
-        case 64: return launch_attn<KIND, 64>(p, B, st);
-        case 128: return launch_attn<KIND, 128>(p, B, st);
+        ATTN_CASE(16)
+        ATTN_CASE(32)
+        ATTN_CASE(64)
+        ATTN_CASE(128)
         default:
             fprintf(stderr, "[ds6g] attention head dim %d not supported (16/32/64/128)\n", hd);
             return DS6G_ERR_ARG;
     }
+#undef ATTN_CASE
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
 }
 
 }  // namespace
 
 extern "C" {
 
+// scratch that lets the split paths use up to 8 splits (forward: partial outputs + (m,l); backward: dk + dv slabs)
+size_t ds6g_attention_workspace_bytes(int B, int T, int nh, int hd, int ld) {
+    const size_t slab = (size_t)B * T * ld * sizeof(float);
+    return 2 * 8 * slab + (size_t)8 * B * nh * T * 2 * sizeof(float);
+}
+
 // o = dropout(softmax(q k^T / sqrt(hd))) v ; lse[b][h][t] = logsumexp of the scaled scores
 int ds6g_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int T, int nh,
-                       int hd, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* stream) {
+                       int hd, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws, size_t ws_bytes,
+                       void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(q && k && v && o && lse && B > 0 && T > 0 && ld % 4 == 0 && ld >= nh * hd);
     DS6G_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
+    const size_t slab = (size_t)B * T * ld;
+    DS6G_CHECK_ARG(slab * sizeof(float) < OOB_OFF);
+    hipStream_t st = (hipStream_t)stream;
     AttnParams p{};
-    p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse; p.T = T; p.nh = nh; p.ld = ld;
+    p.q = q; p.k = k; p.v = v; p.lse = lse; p.T = T; p.nh = nh; p.B = B; p.ld = ld;
+    p.bytes = (unsigned)(slab * sizeof(float)); p.slab = slab;
     p.scale = 1.0f / sqrtf((float)hd);
     p.thr = ds6g_drop_threshold(drop_p); p.dscale = 1.f / (1.f - drop_p); p.seed = seed; p.seed_off = seed_off;
-    return dispatch_hd<0>(p, B, hd, (hipStream_t)stream);
+    const int ntiles = cdiv(T, 32);
+    const int qblocks = cdiv(T, 128);
+    const int per_cu = hd >= 128 ? 2 : 3;
+    const size_t max_by_ws = ws ? ws_bytes / (slab * sizeof(float) + (size_t)B * nh * T * 2 * sizeof(float)) : 1;
+    int splits = pick_splits((long)qblocks * nh * B, ntiles, per_cu, (int)(max_by_ws < 8 ? max_by_ws : 8));
+    if (splits < 1) splits = 1;
+    p.tiles_per_split = cdiv(ntiles, splits);
+    splits = cdiv(ntiles, p.tiles_per_split);
+    p.splits = splits;
+    float* part = (float*)ws;
+    p.o = splits == 1 ? o : part;
+    p.ml = splits == 1 ? nullptr : part + (size_t)splits * slab;
+    int rc = launch_hd<0>(p, hd, dim3(qblocks, nh * splits, B), st);
+    if (rc || splits == 1) return rc;
+    const long n = (long)B * T * (nh * hd / 4);
+    hipLaunchKernelGGL(attn_fwd_merge_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, p.ml, o, lse, B, T, nh, hd, ld,
+                       splits, slab);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
 }
 
 // gradients of the above; delta is a [B][nh][T] scratch (rowsum(dO*O)), written then read
 int ds6g_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                        const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int T, int nh, int hd,
-                       int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* stream) {
+                       int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws, size_t ws_bytes, void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(q && k && v && o && d_o && lse && delta && dq && dk && dv && ld % 4 == 0 && ld >= nh * hd);
+    const size_t slab = (size_t)B * T * ld;
+    DS6G_CHECK_ARG(slab * sizeof(float) < OOB_OFF);
+    hipStream_t st = (hipStream_t)stream;
     AttnParams p{};
     p.q = q; p.k = k; p.v = v; p.o = const_cast<float*>(o); p.lse = const_cast<float*>(lse); p.d_o = d_o;
-    p.delta = delta; p.dq = dq; p.dk = dk; p.dv = dv; p.T = T; p.nh = nh; p.ld = ld;
+    p.delta = delta; p.T = T; p.nh = nh; p.B = B; p.ld = ld;
+    p.bytes = (unsigned)(slab * sizeof(float)); p.slab = slab;
     p.scale = 1.0f / sqrtf((float)hd);
     p.thr = ds6g_drop_threshold(drop_p); p.dscale = 1.f / (1.f - drop_p); p.seed = seed; p.seed_off = seed_off;
-    int rc = dispatch_hd<1>(p, B, hd, (hipStream_t)stream);
-    if (rc) return rc;
-    return dispatch_hd<2>(p, B, hd, (hipStream_t)stream);
+    const int ntiles = cdiv(T, 32);
+    const int blocks128 = cdiv(T, 128);
+    const long n4 = (long)slab / 4;
+    // ---- dQ (split over keys)
+    {
+        const size_t max_by_ws = ws ? ws_bytes / (slab * sizeof(float)) : 1;
+        // workgroups resident per CU (register budget of each instantiation): hd 128 -> 1, 64 -> 2, <= 32 -> 3
+        int splits = pick_splits((long)blocks128 * nh * B, ntiles, hd >= 128 ? 1 : (hd >= 64 ? 2 : 3), (int)(max_by_ws < 8 ? max_by_ws : 8));
+        p.tiles_per_split = cdiv(ntiles, splits);
+        splits = cdiv(ntiles, p.tiles_per_split);
+        p.splits = splits;
+        p.dq = splits == 1 ? dq : (float*)ws;
+        int rc = launch_hd<1>(p, hd, dim3(blocks128, nh * splits, B), st);
+        if (rc) return rc;
+        if (splits > 1) {
+            hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, (const float*)ws, dq, n4, splits, slab);
+            DS6G_LAUNCH_CHECK();
+        }
+    }
+    // ---- dK, dV (split over queries)
+    {
+        const size_t max_by_ws = ws ? ws_bytes / (2 * slab * sizeof(float)) : 1;
+        int splits = pick_splits((long)blocks128 * nh * B, ntiles, hd >= 64 ? 1 : 2, (int)(max_by_ws < 8 ? max_by_ws : 8));
+        p.tiles_per_split = cdiv(ntiles, splits);
+        splits = cdiv(ntiles, p.tiles_per_split);
+        p.splits = splits;
+        float* wsf = (float*)ws;
+        p.dk = splits == 1 ? dk : wsf;
+        p.dv = splits == 1 ? dv : wsf + (size_t)splits * slab;
+        int rc = launch_hd<2>(p, hd, dim3(blocks128, nh * splits, B), st);
+        if (rc) return rc;
+        if (splits > 1) {
+            hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, (const float*)wsf, dk, n4, splits, slab);
+            hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st,
+                               (const float*)(wsf + (size_t)splits * slab), dv, n4, splits, slab);
+            DS6G_LAUNCH_CHECK();
+        }
+    }
+    return DS6G_OK;
 }
 
 }  // extern "C"

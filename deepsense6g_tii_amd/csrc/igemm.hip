@@ -54,36 +54,6 @@ struct IgemmParams {
 
 constexpr int BK = 16;
 
-// One LDS-DMA piece: 64 lanes x 16 B land at lds_base + lane*16 (lane-linear); a lane whose byte offset is
-// >= the descriptor's size (OOB_OFF) gets ZEROS written (measured on gfx950: tools/t_glds.hip) - that is how
-// conv halos, tile tails and k tails are zero-filled without touching a VGPR.
-#define OOB_OFF 0x80000000u
-typedef __attribute__((address_space(3))) void lds_void;
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-// raw buffer descriptor: base, stride 0, num_records = bytes, DATA_FORMAT 32 (gfx9 raw buffer)
-__device__ __forceinline__ i32x4 make_srd(const void* ptr, unsigned bytes) {
-    const unsigned long a = (unsigned long)ptr;
-    return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
-}
-
-// The DMA is issued from inline asm on purpose: hipcc treats a builtin LDS-DMA as aliasing every LDS read and
-// drains vmcnt before the fragment reads of the OTHER buffer, which serialises DMA and MFMA.  From asm the
-// compiler does not see the load; its completion is waited for by the explicit `s_waitcnt vmcnt(0)` ahead of
-// the barrier that precedes the reads.  M0 (LDS destination base) is saved/restored inside the statement.
-__device__ __forceinline__ void dma16(const i32x4 srd, unsigned lds_byte_addr, unsigned voffset) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voffset), "s"(lds_byte_addr), "s"(srd)
-        : "memory");
-}
-
-__device__ __forceinline__ unsigned lds_addr(const float* p) {
-    return (unsigned)(unsigned long)(lds_void*)p;
-}
-
 template <int MODE, int BM, int BN>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int TM = BM / 64;  // 32x32 MFMA tiles per wave along M (wave grid 2x2)

@@ -266,7 +266,7 @@ class TransFuser(nn.Module):
         self._nbt = torch.zeros(len(nb), dtype=torch.long, device=dev)
         for i, b in enumerate(nb):
             b.data = self._nbt[i]
-        self._ws = ops.Workspace(dev, 256 << 20)
+        self._ws = ops.Workspace(dev, 1 << 30)
         self._anchor = torch.zeros(1, dtype=F32, device=dev, requires_grad=True)
         self._pname = {id(p): n for n, p in named}
 
@@ -442,7 +442,7 @@ class TransFuser(nn.Module):
         k = ops.linear_fwd(h, self._w(at.key.weight), self._w(at.key.bias), C)
         v = ops.linear_fwd(h, self._w(at.value.weight), self._w(at.value.bias), C)
         off_a = self._next_drop(B * nh * T * T) if pa > 0 else 0
-        y, lse = ops.attention_fwd(q, k, v, B, T, nh, pa, self._seed, off_a)
+        y, lse = ops.attention_fwd(q, k, v, B, T, nh, self._ws, pa, self._seed, off_a)
         off_p = self._next_drop(x.numel()) if pr > 0 else 0
         x1 = ops.linear_fwd(y, self._w(at.proj.weight), self._w(at.proj.bias), C, residual=x, drop_p=pr,
                             seed=self._seed, seed_off=off_p)
@@ -624,7 +624,7 @@ class TransFuser(nn.Module):
         dz1 = ops.dropout(dx1, pr, self._seed, off_p) if pr > 0 else dx1
         self._lin_param_grads(at.proj, y, dz1)
         dy = ops.linear_dgrad(dz1, self._w(at.proj.weight), C)
-        dq, dk, dv = ops.attention_bwd(q, k, v, y, dy, lse, B, T, nh, pa, self._seed, off_a)
+        dq, dk, dv = ops.attention_bwd(q, k, v, y, dy, lse, B, T, nh, self._ws, pa, self._seed, off_a)
         self._lin_param_grads(at.query, h, dq)
         self._lin_param_grads(at.key, h, dk)
         self._lin_param_grads(at.value, h, dv)

@@ -31,7 +31,7 @@ class Workspace:
     """One caller-owned scratch buffer shared by all kernels of a stream (split-K slabs, BN / LN /
     column-sum partials).  Stream order makes the reuse safe."""
 
-    def __init__(self, device, nbytes=256 << 20):
+    def __init__(self, device, nbytes=1 << 30):
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.nbytes = nbytes
 
@@ -172,7 +172,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma_ptr, dgamma_ptr, dbeta_ptr, ws: Works
 
 
 # ------------------------------------------------------------------------------------------------
-def attention_fwd(q, k, v, B, T, nh, drop_p=0.0, seed=0, seed_off=0):
+def attention_fwd(q, k, v, B, T, nh, ws: Workspace, drop_p=0.0, seed=0, seed_off=0):
     M, C = q.shape
     assert M == B * T
     for t in (q, k, v):
@@ -180,11 +180,11 @@ def attention_fwd(q, k, v, B, T, nh, drop_p=0.0, seed=0, seed_off=0):
     o = torch.empty_like(q)
     lse = torch.empty((B, nh, T), dtype=F32, device=q.device)
     lib().attention_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, T, nh, C // nh, C, float(drop_p), seed, seed_off,
-                        _stream())
+                        ws.ptr, ws.nbytes, _stream())
     return o, lse
 
 
-def attention_bwd(q, k, v, o, d_o, lse, B, T, nh, drop_p=0.0, seed=0, seed_off=0):
+def attention_bwd(q, k, v, o, d_o, lse, B, T, nh, ws: Workspace, drop_p=0.0, seed=0, seed_off=0):
     M, C = q.shape
     for t in (q, k, v, o, d_o):
         _chk(t, M, C)
@@ -192,7 +192,7 @@ def attention_bwd(q, k, v, o, d_o, lse, B, T, nh, drop_p=0.0, seed=0, seed_off=0
     delta = torch.empty_like(lse)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     lib().attention_bwd(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, T, nh,
-                        C // nh, C, float(drop_p), seed, seed_off, _stream())
+                        C // nh, C, float(drop_p), seed, seed_off, ws.ptr, ws.nbytes, _stream())
     return dq, dk, dv
 
 

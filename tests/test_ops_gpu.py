@@ -237,9 +237,11 @@ def test_attention(dev, B, T, nh, hd):
     do = torch.randn(B * T, C, generator=g)
     o.backward(do)
     qg, kg, vg = q.detach().cuda(), k.detach().cuda(), v.detach().cuda()
-    og, lse = ops.attention_fwd(qg, kg, vg, B, T, nh)
+    ws = ops.Workspace(dev, 512 << 20)
+    og, lse = ops.attention_fwd(qg, kg, vg, B, T, nh, ws)
     close(og, o.detach(), 2e-5, 2e-5)
-    dq, dk, dv = ops.attention_bwd(qg, kg, vg, og, do.cuda(), lse, B, T, nh)
+    dog = do.cuda()
+    dq, dk, dv = ops.attention_bwd(qg, kg, vg, og, dog, lse, B, T, nh, ws)
     close(dq, q.grad, 1e-4, 2e-5)
     close(dk, k.grad, 1e-4, 2e-5)
     close(dv, v.grad, 1e-4, 2e-5)
@@ -255,7 +257,9 @@ def test_attention_dropout(dev):
     k = torch.randn(T, hd, generator=g)
     eye = torch.eye(T)  # V = I -> O = dropped probabilities
     p = 0.25
-    og, lse = ops.attention_fwd(q.cuda(), k.cuda(), eye.cuda(), B, T, nh, drop_p=p, seed=99, seed_off=1000)
+    ws = ops.Workspace(dev, 64 << 20)
+    qg, kg, eg = q.cuda(), k.cuda(), eye.cuda()
+    og, lse = ops.attention_fwd(qg, kg, eg, B, T, nh, ws, drop_p=p, seed=99, seed_off=1000)
     att = torch.softmax((q @ k.t()) / math.sqrt(hd), dim=-1)
     pd = og.cpu()
     mask = (pd != 0).float()
@@ -268,10 +272,10 @@ def test_attention_dropout(dev):
     o = ((torch.softmax((qr @ kr.t()) / math.sqrt(hd), dim=-1) * mask / (1 - p)) @ vr)
     do = torch.randn(T, hd, generator=g)
     o.backward(do)
-    og2, lse2 = ops.attention_fwd(q.cuda(), k.cuda(), v.cuda(), B, T, nh, drop_p=p, seed=99, seed_off=1000)
+    vg, dog = v.cuda(), do.cuda()
+    og2, lse2 = ops.attention_fwd(qg, kg, vg, B, T, nh, ws, drop_p=p, seed=99, seed_off=1000)
     close(og2, o.detach(), 2e-5, 2e-5)
-    dq, dk, dv = ops.attention_bwd(q.cuda(), k.cuda(), v.cuda(), og2, do.cuda(), lse2, B, T, nh, drop_p=p, seed=99,
-                                   seed_off=1000)
+    dq, dk, dv = ops.attention_bwd(qg, kg, vg, og2, dog, lse2, B, T, nh, ws, drop_p=p, seed=99, seed_off=1000)
     close(dq, qr.grad, 1e-4, 2e-5)
     close(dk, kr.grad, 1e-4, 2e-5)
     close(dv, vr.grad, 1e-4, 2e-5)
