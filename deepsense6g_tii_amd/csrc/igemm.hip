@@ -54,7 +54,9 @@ struct IgemmParams {
 
 constexpr int BK = 16;
 
-template <int MODE, int BM, int BN>
+// EPI 0: store (or accumulate) only - branch-free bounds handling through a buffer descriptor;
+// EPI 1: full epilogue (bias, ReLU, ReLU-mask, dropout, residual, accumulate, strided-dgrad row remap).
+template <int MODE, int BM, int BN, int EPI>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int TM = BM / 64;  // 32x32 MFMA tiles per wave along M (wave grid 2x2)
     constexpr int TN = BN / 64;
@@ -326,12 +328,39 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
     // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ---------
     float* outp = p.out + ((MODE == MODE_WGRAD) ? (size_t)split * p.split_stride : (size_t)0);
+    if (EPI == 0) {
+        // rows >= Mg land beyond the descriptor (Mg*Ng*4 bytes) and are dropped by the hardware range check;
+        // columns >= Ng are sent there explicitly.  No divergent control flow, one add per store.
+        const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (unsigned)p.Mg * (unsigned)p.Ng * 4u, 0x00020000);
+        const unsigned rowbytes = (unsigned)p.Ng * 4u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+                const int row0 = m0 + wm * (BM / 2) + i * 32 + 4 * khalf;
+                const unsigned base = (col < p.Ng && !((p.dbg & 8) && (i | j)))
+                                          ? (unsigned)row0 * rowbytes + (unsigned)col * 4u
+                                          : OOB_OFF;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned off = base + (unsigned)((r & 3) + 8 * (r >> 2)) * rowbytes;
+                    float v = acc[i][j][r];
+                    // the b32 builtins move raw bits (unsigned): bit-cast, do not convert
+                    if (MODE != MODE_WGRAD && p.accumulate)
+                        v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(o_rsrc, off, 0, 0));
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, off, 0, 0);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-            if (col >= p.Ng || ((p.dbg & 8) && (i | j))) continue;
+            if (col >= p.Ng) continue;
             const float bias = (MODE != MODE_WGRAD && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -391,23 +420,31 @@ int pick_tile(int Mg, int Ng, long splits) {
     return 2;
 }
 
-template <int MODE>
-int launch_igemm(IgemmParams& p, int splits, int tile, hipStream_t st) {
-    p.dbg = g_dbg;
+template <int MODE, int EPI>
+void launch_tile(IgemmParams& p, int splits, int tile, hipStream_t st) {
     dim3 block(256);
     if (tile == 0) {
         p.tiles_n = cdiv(p.Ng, 128);
         dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, 1, splits);
-        hipLaunchKernelGGL((igemm_kernel<MODE, 128, 128>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((igemm_kernel<MODE, 128, 128, EPI>), grid, block, 0, st, p);
     } else if (tile == 1) {
         p.tiles_n = cdiv(p.Ng, 64);
         dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, 1, splits);
-        hipLaunchKernelGGL((igemm_kernel<MODE, 128, 64>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((igemm_kernel<MODE, 128, 64, EPI>), grid, block, 0, st, p);
     } else {
         p.tiles_n = cdiv(p.Ng, 64);
         dim3 grid(cdiv(p.Mg, 64) * p.tiles_n, 1, splits);
-        hipLaunchKernelGGL((igemm_kernel<MODE, 64, 64>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((igemm_kernel<MODE, 64, 64, EPI>), grid, block, 0, st, p);
     }
+}
+
+template <int MODE>
+int launch_igemm(IgemmParams& p, int splits, int tile, hipStream_t st) {
+    p.dbg = g_dbg;
+    const bool full = p.bias || p.relu || p.mask_src || p.drop_thr || p.residual || (MODE == MODE_DGRAD && p.hstep != 1);
+    if ((size_t)p.Mg * p.Ng * sizeof(float) >= OOB_OFF) return DS6G_ERR_ARG;
+    if (MODE != MODE_WGRAD && full) launch_tile<MODE, 1>(p, splits, tile, st);
+    else launch_tile<MODE, 0>(p, splits, tile, st);
     g_last_variant = MODE * 10 + tile;
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
