@@ -52,20 +52,22 @@ struct IgemmParams {
     int dbg;  // ablation flags (timing experiments only): 1 skip in-loop global loads, 2 skip LDS stores, 4 skip barrier
 };
 
-constexpr int BK = 16;
 
 // EPI 0: store (or accumulate) only - branch-free bounds handling through a buffer descriptor;
 // EPI 1: full epilogue (bias, ReLU, ReLU-mask, dropout, residual, accumulate, strided-dgrad row remap).
-template <int MODE, int BM, int BN, int EPI>
+template <int MODE, int BM, int BN, int EPI, int BK>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+    constexpr int CH = BK / 4;              // 16-B chunks per K-contiguous row
+    constexpr int RPB = 16 / CH;            // rows per 256-B LDS bank row
+    constexpr int KH = BK / 2;              // k values per lane half
     constexpr int TM = BM / 64;  // 32x32 MFMA tiles per wave along M (wave grid 2x2)
     constexpr int TN = BN / 64;
-    constexpr int A_LD = BM * 4 / 256;  // 16-B DMA pieces per thread per k-tile
-    constexpr int B_LD = BN * 4 / 256;
+    constexpr int A_LD = BM * CH / 256;  // 16-B DMA pieces per thread per k-tile
+    constexpr int B_LD = BN * CH / 256;
     constexpr bool A_KMAJOR = (MODE == MODE_WGRAD);  // A source contiguous along rows (m): image [k][BM]
     constexpr bool B_KMAJOR = (MODE != MODE_FWD);    // B source contiguous along rows (n): image [k][BN]
-    // K-contiguous sources: image [row][16] (64-B rows, no padding - the DMA destination is lane-linear) with the
-    // 16-B chunk index XOR-swizzled by (row>>2)&3 on the SOURCE side; readers apply the same XOR.
+    // K-contiguous sources: image [row][BK] (no padding - the DMA destination is lane-linear) with the 16-B chunk
+    // index XOR-swizzled by (row / RPB) & (CH-1) on the SOURCE side; readers apply the same XOR.
     // four separate objects (not [2][..] arrays): the compiler must be able to prove that the fragment reads of
     // one buffer do not alias the DMA in flight into the other, or it drains vmcnt before every read
     __shared__ __attribute__((aligned(16))) float As0[BM * BK];
@@ -107,12 +109,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     for (int i = 0; i < A_LD; ++i) {
         const int idx = tid + i * 256;
         if (MODE == MODE_FWD || MODE == MODE_DGRAD) {
-            const int row = idx >> 2;
+            const int row = idx / CH;
             const int m = m0 + row;
             a_ok[i] = m < p.Mg;
             const int mm = a_ok[i] ? m : 0;
             const int cin = (MODE == MODE_FWD) ? p.C : p.K;
-            const int kg = ((idx & 3) ^ ((row >> 2) & 3)) * 4;  // swizzled source chunk
+            const int kg = ((idx % CH) ^ ((row / RPB) & (CH - 1))) * 4;  // swizzled source chunk
             a_k[i] = kg;
             const int tap = kg / cin;
             a_c[i] = kg - tap * cin;
@@ -155,9 +157,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         const int idx = tid + i * 256;
         b_r[i] = b_s[i] = b_o[i] = b_t[i] = b_n[i] = 0;
         if (MODE == MODE_FWD) {
-            const int row = idx >> 2;
+            const int row = idx / CH;
             b_ok[i] = (n0 + row) < p.Ng;
-            b_k[i] = ((idx & 3) ^ ((row >> 2) & 3)) * 4;
+            b_k[i] = ((idx % CH) ^ ((row / RPB) & (CH - 1))) * 4;
             b_base[i] = (unsigned)(n0 + row) * (unsigned)p.Kg;
         } else if (MODE == MODE_DGRAD) {
             b_ok[i] = (n0 + (idx % (BN / 4)) * 4) < p.Ng;
@@ -267,36 +269,41 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int a_row = wm * (BM / 2) + (lane & 31);
     const int b_row = wn * (BN / 2) + (lane & 31);
     const int khalf = lane >> 5;
-    const int swz = ((lane & 31) >> 2) & 3;          // (row >> 2) & 3 of every fragment row of this lane
-    const int p0 = ((2 * khalf) ^ swz) * 4, p1 = ((2 * khalf + 1) ^ swz) * 4;
+    const int swz = ((lane & 31) / RPB) & (CH - 1);  // chunk XOR of every fragment row of this lane
 
     // one k-tile: start the DMA of the next tile into (An, Bn), multiply the tile resident in (Ac, Bc)
     auto k_step = [&](const float* Ac, const float* Bc, float* An, float* Bn, bool more) {
         if (more && !(p.dbg & 1)) issue_tiles(An, Bn);
-        // fragments: lane (row, khalf) holds tile columns 8*khalf .. 8*khalf+7 of its row
-        float af[TM][8], bf[TN][8];
+        // fragments: lane (row, khalf) holds tile columns KH*khalf .. KH*khalf+KH-1 of its row
+        float af[TM][KH], bf[TN][KH];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if (A_KMAJOR) {
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) af[i][kk] = Ac[(khalf * 8 + kk) * BM + a_row + i * 32];
+                for (int kk = 0; kk < KH; ++kk) af[i][kk] = Ac[(khalf * KH + kk) * BM + a_row + i * 32];
             } else {
                 const float* rp = &Ac[(a_row + i * 32) * BK];
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp + p0), v1 = *reinterpret_cast<const f32x4*>(rp + p1);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) { af[i][kk] = v0[kk]; af[i][4 + kk] = v1[kk]; }
+                for (int c = 0; c < CH / 2; ++c) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(rp + (((khalf * (CH / 2) + c) ^ swz) << 2));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) af[i][4 * c + e] = v[e];
+                }
             }
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             if (B_KMAJOR) {
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) bf[j][kk] = Bc[(khalf * 8 + kk) * BN + b_row + j * 32];
+                for (int kk = 0; kk < KH; ++kk) bf[j][kk] = Bc[(khalf * KH + kk) * BN + b_row + j * 32];
             } else {
                 const float* rp = &Bc[(b_row + j * 32) * BK];
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp + p0), v1 = *reinterpret_cast<const f32x4*>(rp + p1);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) { bf[j][kk] = v0[kk]; bf[j][4 + kk] = v1[kk]; }
+                for (int c = 0; c < CH / 2; ++c) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(rp + (((khalf * (CH / 2) + c) ^ swz) << 2));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bf[j][4 * c + e] = v[e];
+                }
             }
         }
         // keep every fragment read ahead of the MFMA chain (the scheduler otherwise sinks each read next to
@@ -420,21 +427,21 @@ int pick_tile(int Mg, int Ng, long splits) {
     return 2;
 }
 
-template <int MODE, int EPI>
+template <int MODE, int EPI, int BKV>
 void launch_tile(IgemmParams& p, int splits, int tile, hipStream_t st) {
     dim3 block(256);
     if (tile == 0) {
         p.tiles_n = cdiv(p.Ng, 128);
         dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, 1, splits);
-        hipLaunchKernelGGL((igemm_kernel<MODE, 128, 128, EPI>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((igemm_kernel<MODE, 128, 128, EPI, BKV>), grid, block, 0, st, p);
     } else if (tile == 1) {
         p.tiles_n = cdiv(p.Ng, 64);
         dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, 1, splits);
-        hipLaunchKernelGGL((igemm_kernel<MODE, 128, 64, EPI>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((igemm_kernel<MODE, 128, 64, EPI, BKV>), grid, block, 0, st, p);
     } else {
         p.tiles_n = cdiv(p.Ng, 64);
         dim3 grid(cdiv(p.Mg, 64) * p.tiles_n, 1, splits);
-        hipLaunchKernelGGL((igemm_kernel<MODE, 64, 64, EPI>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((igemm_kernel<MODE, 64, 64, EPI, BKV>), grid, block, 0, st, p);
     }
 }
 
@@ -443,8 +450,9 @@ int launch_igemm(IgemmParams& p, int splits, int tile, hipStream_t st) {
     p.dbg = g_dbg;
     const bool full = p.bias || p.relu || p.mask_src || p.drop_thr || p.residual || (MODE == MODE_DGRAD && p.hstep != 1);
     if ((size_t)p.Mg * p.Ng * sizeof(float) >= OOB_OFF) return DS6G_ERR_ARG;
-    if (MODE != MODE_WGRAD && full) launch_tile<MODE, 1>(p, splits, tile, st);
-    else launch_tile<MODE, 0>(p, splits, tile, st);
+    // BK = 32 was measured (tools/bench_igemm.py): within +-5 % on fwd/dgrad, 10-30 % slower on wgrad -> BK = 16
+    if (MODE != MODE_WGRAD && full) launch_tile<MODE, 1, 16>(p, splits, tile, st);
+    else launch_tile<MODE, 0, 16>(p, splits, tile, st);
     g_last_variant = MODE * 10 + tile;
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
@@ -467,12 +475,12 @@ int run_wgrad(IgemmParams& p, float* dw, int accumulate, float* ws, size_t ws_by
     // linears (large outputs, costlier slab reduction) with ~1024
     const long target_blocks = (p.R * p.S == 1 && p.H * p.W == 1) ? 1024 : 2048;
     long splits = (target_blocks + tiles - 1) / tiles;
-    const long max_by_k = (p.Kg + 4 * BK - 1) / (4 * BK);
+    const long max_by_k = (p.Kg + 64 - 1) / 64;
     if (splits > max_by_k) splits = max_by_k;
     const long max_by_ws = (long)(ws_bytes / (out_elems * sizeof(float)));
     if (splits > max_by_ws) splits = max_by_ws;
     if (splits < 1) splits = 1;
-    int kps = cdiv(cdiv(p.Kg, splits), BK) * BK;
+    int kps = cdiv(cdiv(p.Kg, splits), 32) * 32;
     splits = cdiv(p.Kg, kps);
     p.k_per_split = kps;
     p.split_stride = (size_t)out_elems;
