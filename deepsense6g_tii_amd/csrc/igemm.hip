@@ -45,6 +45,7 @@ struct IgemmParams {
     int k_per_split;     // multiple of 16
     size_t split_stride; // elements between split-K slabs
     int tiles_n;
+    int want_colsum;     // WGRAD: also emit column sums of the A operand (bias gradient) behind each slab
     // DGRAD of a strided conv is run per input-pixel parity class: pixels h = h0 + hstep*hh (hh < Hs), taps
     // r = r0 + rstep*ri (ri < nr) - only the taps that hit a real output pixel, no structural zeros
     int h0, hstep, Hs, w0, wstep, Ws, r0, rstep, nr, s0, sstep, ns;
@@ -272,8 +273,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int swz = ((lane & 31) / RPB) & (CH - 1);  // chunk XOR of every fragment row of this lane
 
     // one k-tile: start the DMA of the next tile into (An, Bn), multiply the tile resident in (Ac, Bc)
+    float csum = 0.f;  // WGRAD bias gradient: column sum of the dy tile, owned by thread tid < BM of tile_n == 0 blocks
+    const bool do_csum = (MODE == MODE_WGRAD) && p.want_colsum && tile_n == 0 && tid < BM;
     auto k_step = [&](const float* Ac, const float* Bc, float* An, float* Bn, bool more) {
         if (more && !(p.dbg & 1)) issue_tiles(An, Bn);
+        if (MODE == MODE_WGRAD && do_csum) {
+#pragma unroll
+            for (int k = 0; k < BK; ++k) csum += Ac[k * BM + tid];
+        }
         // fragments: lane (row, khalf) holds tile columns KH*khalf .. KH*khalf+KH-1 of its row
         float af[TM][KH], bf[TN][KH];
 #pragma unroll
@@ -335,6 +342,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
     // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ---------
     float* outp = p.out + ((MODE == MODE_WGRAD) ? (size_t)split * p.split_stride : (size_t)0);
+    if (MODE == MODE_WGRAD && do_csum && m0 + tid < p.Mg) outp[(size_t)p.Mg * p.Ng + m0 + tid] = csum;
     if (EPI == 0) {
         // rows >= Mg land beyond the descriptor (Mg*Ng*4 bytes) and are dropped by the hardware range check;
         // columns >= Ng are sent there explicitly.  No divergent control flow, one add per store.
@@ -397,20 +405,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_s part[s*stride + i].  256 threads = 64 float4 columns x 4 split-lanes.
+// The slab holds n4 float4 of weight gradient followed (optionally) by m4 float4 of bias gradient -> out_b.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                            long n4, int splits, size_t stride, int accumulate) {
+                                                            long n4, float* __restrict__ out_b, long m4, int splits,
+                                                            size_t stride, int accumulate, int accumulate_b) {
     __shared__ f32x4 red[4][64];
     const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * 64 + col;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (i < n4)
+    if (i < n4 + m4)
         for (int k = sl; k < splits; k += 4) s += *reinterpret_cast<const f32x4*>(part + (size_t)k * stride + i * 4);
     red[sl][col] = s;
     __syncthreads();
-    if (sl != 0 || i >= n4) return;
+    if (sl != 0 || i >= n4 + m4) return;
     s += red[1][col] + red[2][col] + red[3][col];
-    f32x4* o = reinterpret_cast<f32x4*>(out + i * 4);
-    if (accumulate) s += *o;
+    const bool is_b = i >= n4;
+    f32x4* o = is_b ? reinterpret_cast<f32x4*>(out_b + (i - n4) * 4) : reinterpret_cast<f32x4*>(out + i * 4);
+    if (is_b ? accumulate_b : accumulate) s += *o;
     *o = s;
 }
 
@@ -463,12 +474,13 @@ int launch_igemm(IgemmParams& p, hipStream_t st) {
     return launch_igemm<MODE>(p, 1, pick_tile(p.Mg, p.Ng, 1), st);
 }
 
-int run_wgrad(IgemmParams& p, float* dw, int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
+int run_wgrad(IgemmParams& p, float* dw, int accumulate, float* dbias, int accumulate_b, float* ws, size_t ws_bytes,
+              hipStream_t st) {
     const long out_elems = (long)p.Mg * p.Ng;
-    DS6G_CHECK_ARG(out_elems % 4 == 0);
+    DS6G_CHECK_ARG(out_elems % 4 == 0 && p.Mg % 4 == 0);
+    const long slab_elems = out_elems + (dbias ? p.Mg : 0);
     // the output (a weight tensor) has few tiles and the reduction (pixels) is long: split K until the grid
-    // holds ~6 workgroups per CU (latency hiding needs the occupancy), bounded by the workspace and by
-    // >= 4 k-tiles per split
+    // holds enough workgroups for latency hiding, bounded by the workspace and by >= 4 k-tiles per split
     const int tile = (p.Mg >= 128) ? 1 : 2;
     const long tiles = (long)cdiv(p.Mg, tile == 1 ? 128 : 64) * cdiv(p.Ng, 64);
     // measured on gfx950 (tools/bench_igemm.py): convs are fastest with ~2048 workgroups in flight, the GPT
@@ -477,23 +489,25 @@ int run_wgrad(IgemmParams& p, float* dw, int accumulate, float* ws, size_t ws_by
     long splits = (target_blocks + tiles - 1) / tiles;
     const long max_by_k = (p.Kg + 64 - 1) / 64;
     if (splits > max_by_k) splits = max_by_k;
-    const long max_by_ws = (long)(ws_bytes / (out_elems * sizeof(float)));
+    const long max_by_ws = (long)(ws_bytes / (slab_elems * sizeof(float)));
     if (splits > max_by_ws) splits = max_by_ws;
     if (splits < 1) splits = 1;
     int kps = cdiv(cdiv(p.Kg, splits), 32) * 32;
     splits = cdiv(p.Kg, kps);
     p.k_per_split = kps;
-    p.split_stride = (size_t)out_elems;
-    if (splits == 1 && !accumulate) {
+    p.split_stride = (size_t)slab_elems;
+    p.want_colsum = dbias != nullptr;
+    if (splits == 1 && !accumulate && !dbias) {
         p.out = dw;
         return launch_igemm<MODE_WGRAD>(p, 1, tile, st);
     }
-    DS6G_CHECK_ARG(ws != nullptr && (size_t)splits * out_elems * sizeof(float) <= ws_bytes);
+    DS6G_CHECK_ARG(ws != nullptr && (size_t)splits * slab_elems * sizeof(float) <= ws_bytes);
     p.out = ws;
     int rc = launch_igemm<MODE_WGRAD>(p, (int)splits, tile, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(out_elems / 4, 64)), dim3(256), 0, st, ws, dw, out_elems / 4,
-                       (int)splits, (size_t)out_elems, accumulate);
+    const long n4 = out_elems / 4, m4 = dbias ? p.Mg / 4 : 0;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n4 + m4, 64)), dim3(256), 0, st, ws, dw, n4, dbias, m4,
+                       (int)splits, (size_t)slab_elems, accumulate, accumulate_b);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }
@@ -581,7 +595,7 @@ int ds6g_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
     DS6G_CHECK_ARG(cb.ok);
     p.a_bytes = (unsigned)cb.y; p.b_bytes = (unsigned)cb.x;
     p.Mg = K; p.Ng = R * S * C; p.Kg = N * p.Ho * p.Wo;
-    return run_wgrad(p, dw, accumulate, ws, ws_bytes, (hipStream_t)stream);
+    return run_wgrad(p, dw, accumulate, nullptr, 0, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // y[M][N] = residual + dropout( act( x[M][K] @ w[N][K]^T + bias ) )
@@ -617,9 +631,9 @@ int ds6g_linear_dgrad(const float* dy, const float* w, float* dx, int M, int N, 
     return launch_igemm<MODE_DGRAD>(p, (hipStream_t)stream);
 }
 
-// dw[N][K] (+)= dy[M][N]^T @ x[M][K]
-int ds6g_linear_wgrad(const float* x, const float* dy, float* dw, int M, int N, int K, int accumulate, float* ws,
-                      size_t ws_bytes, void* stream) {
+// dw[N][K] (+)= dy[M][N]^T @ x[M][K];  dbias[N] (+)= column sums of dy (nullable; fused into the same kernel)
+int ds6g_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, int M, int N, int K, int accumulate,
+                      float* ws, size_t ws_bytes, void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(x && dy && dw && K % 4 == 0 && N % 4 == 0);
     IgemmParams p;
@@ -629,7 +643,7 @@ int ds6g_linear_wgrad(const float* x, const float* dy, float* dw, int M, int N, 
     DS6G_CHECK_ARG(cb.ok);
     p.a_bytes = (unsigned)cb.y; p.b_bytes = (unsigned)cb.x;
     p.Mg = N; p.Ng = K; p.Kg = M;
-    return run_wgrad(p, dw, accumulate, ws, ws_bytes, (hipStream_t)stream);
+    return run_wgrad(p, dw, accumulate, dbias, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

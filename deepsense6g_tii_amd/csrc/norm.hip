@@ -205,95 +205,121 @@ int bn_geometry(long M, int C, int* rows_per_block, int* nblk) {
 }
 
 // ------------------------------------ LayerNorm ----------------------------------------------
-// one wave per row, lane owns columns lane + 64 j  (C <= 512, C % 64 == 0)
-template <int NJ>
+// one wave per row; a lane owns columns 4*lane + 256*j + {0..3} (16-B accesses) when C >= 256, else the
+// scalar columns lane + 64*j.  C in {64,128,256,512}.
+template <int C>
+struct LnRow {
+    static constexpr bool VEC = C >= 256;
+    static constexpr int NV = VEC ? C / 256 : C / 64;  // float4 (VEC) or float (scalar) items per lane
+    static constexpr int NE = VEC ? 4 * NV : NV;       // elements per lane
+    __device__ static void load(float* v, const float* row, int lane) {
+        if (VEC) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(row + 4 * lane + 256 * j);
+                v[4 * j] = t[0]; v[4 * j + 1] = t[1]; v[4 * j + 2] = t[2]; v[4 * j + 3] = t[3];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] = row[lane + 64 * j];
+        }
+    }
+    __device__ static void store(const float* v, float* row, int lane) {
+        if (VEC) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                *reinterpret_cast<f32x4*>(row + 4 * lane + 256 * j) = f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) row[lane + 64 * j] = v[j];
+        }
+    }
+    __device__ static int col(int e, int lane) { return VEC ? 4 * lane + 256 * (e >> 2) + (e & 3) : lane + 64 * e; }
+};
+
+template <int C>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M,
                                                      float eps) {
-    constexpr int C = NJ * 64;
+    using R = LnRow<C>;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float* xr = x + (size_t)row * C;
-    float v[NJ];
+    float v[R::NE], g[R::NE], b[R::NE];
+    R::load(v, x + (size_t)row * C, lane);
+    R::load(g, gamma, lane);
+    R::load(b, beta, lane);
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        v[j] = xr[lane + 64 * j];
-        s += v[j];
-    }
+    for (int e = 0; e < R::NE; ++e) s += v[e];
     const float mu = wave_reduce_sum(s) * (1.0f / C);
     float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const float d = v[j] - mu;
+    for (int e = 0; e < R::NE; ++e) {
+        const float d = v[e] - mu;
         q += d * d;
     }
     const float rs = 1.0f / sqrtf(wave_reduce_sum(q) * (1.0f / C) + eps);
-    float* yr = y + (size_t)row * C;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int c = lane + 64 * j;
-        yr[c] = (v[j] - mu) * rs * gamma[c] + beta[c];
-    }
+    for (int e = 0; e < R::NE; ++e) v[e] = (v[e] - mu) * rs * g[e] + b[e];
+    R::store(v, y + (size_t)row * C, lane);
     if (lane == 0) {
         mean[row] = mu;
         rstd[row] = rs;
     }
 }
 
-constexpr int LN_BWD_ROWS = 64;  // rows per block (16 per wave)
+constexpr int LN_BWD_ROWS = 16;  // rows per block (4 per wave): >= 700 blocks at M = 11544
 
-template <int NJ>
+template <int C>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ add,
                                                      float* __restrict__ dx, float* __restrict__ partial, int M) {
-    constexpr int C = NJ * 64;
+    using R = LnRow<C>;
     __shared__ float red[4][2][C];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float g[NJ], dg[NJ], db[NJ];
+    float g[R::NE], dg[R::NE], db[R::NE];
+    R::load(g, gamma, lane);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        g[j] = gamma[lane + 64 * j];
-        dg[j] = 0.f;
-        db[j] = 0.f;
-    }
+    for (int e = 0; e < R::NE; ++e) { dg[e] = 0.f; db[e] = 0.f; }
     const int rbase = blockIdx.x * LN_BWD_ROWS + wave * (LN_BWD_ROWS / 4);
     for (int rr = 0; rr < LN_BWD_ROWS / 4; ++rr) {
         const int row = rbase + rr;
         if (row >= M) break;
         const size_t o = (size_t)row * C;
         const float mu = mean[row], rs = rstd[row];
-        float dyv[NJ], xh[NJ];
+        float dyv[R::NE], xh[R::NE];
+        R::load(dyv, dy + o, lane);
+        R::load(xh, x + o, lane);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int c = lane + 64 * j;
-            dyv[j] = dy[o + c];
-            xh[j] = (x[o + c] - mu) * rs;
-            const float t = dyv[j] * g[j];
+        for (int e = 0; e < R::NE; ++e) {
+            xh[e] = (xh[e] - mu) * rs;
+            const float t = dyv[e] * g[e];
             s1 += t;
-            s2 += t * xh[j];
-            dg[j] += dyv[j] * xh[j];
-            db[j] += dyv[j];
+            s2 += t * xh[e];
+            dg[e] += dyv[e] * xh[e];
+            db[e] += dyv[e];
         }
         s1 = wave_reduce_sum(s1) * (1.0f / C);
         s2 = wave_reduce_sum(s2) * (1.0f / C);
+        float av[R::NE];
+        if (add) R::load(av, add + o, lane);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int c = lane + 64 * j;
-            float v = rs * (dyv[j] * g[j] - s1 - xh[j] * s2);
-            if (add) v += add[o + c];
-            dx[o + c] = v;
+        for (int e = 0; e < R::NE; ++e) {
+            float v = rs * (dyv[e] * g[e] - s1 - xh[e] * s2);
+            if (add) v += av[e];
+            dyv[e] = v;
         }
+        R::store(dyv, dx + o, lane);
     }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        red[wave][0][lane + 64 * j] = dg[j];
-        red[wave][1][lane + 64 * j] = db[j];
+    for (int e = 0; e < R::NE; ++e) {
+        red[wave][0][R::col(e, lane)] = dg[e];
+        red[wave][1][R::col(e, lane)] = db[e];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * C; i += 256) {
@@ -432,10 +458,10 @@ int ds6g_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
     dim3 grid(cdiv(M, 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     switch (C / 64) {
-        case 1: hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
-        case 2: hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
-        case 4: hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
-        case 8: hipLaunchKernelGGL((ln_fwd_kernel<8>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
+        case 1: hipLaunchKernelGGL((ln_fwd_kernel<64>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
+        case 2: hipLaunchKernelGGL((ln_fwd_kernel<128>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
+        case 4: hipLaunchKernelGGL((ln_fwd_kernel<256>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
+        case 8: hipLaunchKernelGGL((ln_fwd_kernel<512>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
         default: DS6G_CHECK_ARG(!"LayerNorm width must be 64/128/256/512");
     }
     DS6G_LAUNCH_CHECK();
@@ -457,10 +483,10 @@ int ds6g_layernorm_bwd(const float* dy, const float* x, const float* mean, const
     dim3 grid(nblk), block(256);
     hipStream_t st = (hipStream_t)stream;
     switch (C / 64) {
-        case 1: hipLaunchKernelGGL((ln_bwd_kernel<1>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M); break;
-        case 2: hipLaunchKernelGGL((ln_bwd_kernel<2>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M); break;
-        case 4: hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M); break;
-        case 8: hipLaunchKernelGGL((ln_bwd_kernel<8>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M); break;
+        case 1: hipLaunchKernelGGL((ln_bwd_kernel<64>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M); break;
+        case 2: hipLaunchKernelGGL((ln_bwd_kernel<128>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M); break;
+        case 4: hipLaunchKernelGGL((ln_bwd_kernel<256>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M); break;
+        case 8: hipLaunchKernelGGL((ln_bwd_kernel<512>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M); break;
         default: DS6G_CHECK_ARG(!"LayerNorm width must be 64/128/256/512");
     }
     DS6G_LAUNCH_CHECK();

@@ -581,8 +581,7 @@ class TransFuser(nn.Module):
     def _lin_param_grads(self, lin, x, dy):
         gw, aw = self._g(lin.weight)
         gb, ab = self._g(lin.bias)
-        ops.linear_wgrad(x, dy, gw, self._ws, accumulate=bool(aw))
-        ops.colsum(dy, gb, self._ws, accumulate=bool(ab))
+        ops.linear_wgrad(x, dy, gw, self._ws, accumulate=bool(aw), dbias_ptr=gb)
 
     def _block_bwd(self, blk, ctx, dout, need_dx=True):
         x, c1, a1, s1, c2, s2, cd, sd, out = ctx

@@ -99,13 +99,14 @@ def linear_dgrad(dy, w_ptr, K, relu_mask_src=None, out=None, accumulate=False):
     return dx
 
 
-def linear_wgrad(x, dy, dw_ptr, ws: Workspace, accumulate=False):
+def linear_wgrad(x, dy, dw_ptr, ws: Workspace, accumulate=False, dbias_ptr=0):
+    """dw (+)= dy^T x and, when dbias_ptr is given, dbias (+)= column sums of dy from the same kernel."""
     M, K = x.shape
     M2, N = dy.shape
     assert M == M2
     _chk(x)
     _chk(dy)
-    lib().linear_wgrad(_p(x), _p(dy), dw_ptr, M, N, K, int(accumulate), ws.ptr, ws.nbytes, _stream())
+    lib().linear_wgrad(_p(x), _p(dy), dw_ptr, dbias_ptr, M, N, K, int(accumulate), ws.ptr, ws.nbytes, _stream())
 
 
 def colsum(x, out_ptr, ws: Workspace, accumulate=False):

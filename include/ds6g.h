@@ -44,8 +44,8 @@ int ds6g_linear_fwd(const float* x, const float* w, const float* bias, float* y,
                     const float* residual, float drop_p, uint64_t seed, uint64_t seed_off, void* stream);
 int ds6g_linear_dgrad(const float* dy, const float* w, float* dx, int M, int N, int K, const float* relu_mask_src,
                       int accumulate, void* stream);
-int ds6g_linear_wgrad(const float* x, const float* dy, float* dw, int M, int N, int K, int accumulate, float* ws,
-                      size_t ws_bytes, void* stream);
+int ds6g_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, int M, int N, int K, int accumulate,
+                      float* ws, size_t ws_bytes, void* stream);
 
 /* ---- norm.hip ----------------------------------------------------------------------------------
  * BatchNorm2d in train mode (+ReLU, +residual add of BasicBlock): torchvision BasicBlock via

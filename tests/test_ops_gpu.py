@@ -116,6 +116,15 @@ def test_linear(dev, M, N, K):
     dbg = torch.empty_like(bg)
     ops.colsum(dmask.cuda(), dbg.data_ptr(), ws)
     close(dbg, b.grad, 1e-4, 1e-4)
+    # fused weight + bias gradient from one kernel, and its accumulate form
+    dw2, db2 = torch.full_like(wg, 7.0), torch.full_like(bg, 7.0)
+    dmg = dmask.cuda()
+    ops.linear_wgrad(xg, dmg, dw2.data_ptr(), ws, dbias_ptr=db2.data_ptr())
+    close(dw2, w.grad, 1e-4, 1e-4)
+    close(db2, b.grad, 1e-4, 1e-4)
+    ops.linear_wgrad(xg, dmg, dw2.data_ptr(), ws, accumulate=True, dbias_ptr=db2.data_ptr())
+    close(dw2, 2 * w.grad, 1e-4, 1e-4)
+    close(db2, 2 * b.grad, 1e-4, 1e-4)
     ops.colsum(dmask.cuda(), dbg.data_ptr(), ws, accumulate=True)
     close(dbg, 2 * b.grad, 1e-4, 1e-4)
     del hg, dyg
