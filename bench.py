@@ -106,15 +106,12 @@ class IgemmTimer:
             Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - S) // st + 1
             return 2.0 * N * Ho * Wo * K * R * S * C
 
-        def lin_flops(a):  # fwd: (x,w,b,y,M,N,K,...); dgrad: (dy,w,dx,M,N,K,...); wgrad: (x,dy,dw,M,N,K,...)
-            return None
-
         wrap("conv2d_fwd", conv_flops)
         wrap("conv2d_dgrad", conv_flops)
         wrap("conv2d_wgrad", conv_flops)
         wrap("linear_fwd", lambda a: 2.0 * a[4] * a[5] * a[6])
         wrap("linear_dgrad", lambda a: 2.0 * a[3] * a[4] * a[5])
-        wrap("linear_wgrad", lambda a: 2.0 * a[3] * a[4] * a[5])
+        wrap("linear_wgrad", lambda a: 2.0 * a[4] * a[5] * a[6])  # (x, dy, dw, dbias, M, N, K, ...)
 
     def uninstall(self):
         from deepsense6g_tii_amd._lib import lib

@@ -404,21 +404,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_s part[s*stride + i].  256 threads = 64 float4 columns x 4 split-lanes.
+// out[i] = (accumulate ? out[i] : 0) + sum_s part[s*stride + i].  256 threads = 16 float4 columns x 16 split-lanes
+// (small outputs with many splits are latency-bound: spread the splits over lanes, keep many loads in flight).
 // The slab holds n4 float4 of weight gradient followed (optionally) by m4 float4 of bias gradient -> out_b.
+constexpr int RED_COLS = 16, RED_LANES = 16;
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                             long n4, float* __restrict__ out_b, long m4, int splits,
                                                             size_t stride, int accumulate, int accumulate_b) {
-    __shared__ f32x4 red[4][64];
-    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const long i = (long)blockIdx.x * 64 + col;
+    __shared__ f32x4 red[RED_LANES][RED_COLS];
+    const int col = threadIdx.x & (RED_COLS - 1), sl = threadIdx.x / RED_COLS;
+    const long i = (long)blockIdx.x * RED_COLS + col;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (i < n4 + m4)
-        for (int k = sl; k < splits; k += 4) s += *reinterpret_cast<const f32x4*>(part + (size_t)k * stride + i * 4);
+        for (int k = sl; k < splits; k += RED_LANES) s += *reinterpret_cast<const f32x4*>(part + (size_t)k * stride + i * 4);
     red[sl][col] = s;
     __syncthreads();
     if (sl != 0 || i >= n4 + m4) return;
-    s += red[1][col] + red[2][col] + red[3][col];
+#pragma unroll
+    for (int l = 1; l < RED_LANES; ++l) s += red[l][col];
     const bool is_b = i >= n4;
     f32x4* o = is_b ? reinterpret_cast<f32x4*>(out_b + (i - n4) * 4) : reinterpret_cast<f32x4*>(out + i * 4);
     if (is_b ? accumulate_b : accumulate) s += *o;
@@ -430,11 +433,13 @@ int g_last_variant = -1;
 int g_dbg = 0;
 
 // tile choice: 0 = 128x128, 1 = 128x64, 2 = 64x64 - the largest tile that still yields >= 384 workgroups
+int g_min_blocks = 2560;  // measured: many small (64x64, 8 waves/SIMD) workgroups beat larger tiles up to here
+int g_wgrad_tile = 1;
 int pick_tile(int Mg, int Ng, long splits) {
     const long t128 = (long)cdiv(Mg, 128) * cdiv(Ng, 128) * splits;
     const long t12864 = (long)cdiv(Mg, 128) * cdiv(Ng, 64) * splits;
-    if (Ng > 64 && Mg > 64 && t128 >= 384) return 0;
-    if (Mg > 64 && t12864 >= 384) return 1;
+    if (Ng > 64 && Mg > 64 && t128 >= g_min_blocks) return 0;
+    if (Mg > 64 && t12864 >= g_min_blocks) return 1;
     return 2;
 }
 
@@ -481,7 +486,7 @@ int run_wgrad(IgemmParams& p, float* dw, int accumulate, float* dbias, int accum
     const long slab_elems = out_elems + (dbias ? p.Mg : 0);
     // the output (a weight tensor) has few tiles and the reduction (pixels) is long: split K until the grid
     // holds enough workgroups for latency hiding, bounded by the workspace and by >= 4 k-tiles per split
-    const int tile = (p.Mg >= 128) ? 1 : 2;
+    const int tile = (p.Mg >= 128 && g_wgrad_tile == 1) ? 1 : 2;
     const long tiles = (long)cdiv(p.Mg, tile == 1 ? 128 : 64) * cdiv(p.Ng, 64);
     // measured on gfx950 (tools/bench_igemm.py): convs are fastest with ~2048 workgroups in flight, the GPT
     // linears (large outputs, costlier slab reduction) with ~1024
@@ -506,7 +511,7 @@ int run_wgrad(IgemmParams& p, float* dw, int accumulate, float* dbias, int accum
     int rc = launch_igemm<MODE_WGRAD>(p, (int)splits, tile, st);
     if (rc) return rc;
     const long n4 = out_elems / 4, m4 = dbias ? p.Mg / 4 : 0;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n4 + m4, 64)), dim3(256), 0, st, ws, dw, n4, dbias, m4,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n4 + m4, RED_COLS)), dim3(256), 0, st, ws, dw, n4, dbias, m4,
                        (int)splits, (size_t)slab_elems, accumulate, accumulate_b);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
@@ -538,7 +543,12 @@ ConvBytes conv_bytes(const IgemmParams& p) {
 extern "C" {
 
 int ds6g_last_igemm_variant(void) { return g_last_variant; }
-int ds6g_set_debug_flags(int flags) { g_dbg = flags; return 0; }
+int ds6g_set_debug_flags(int flags) {
+    g_dbg = flags & 0x3f;
+    g_wgrad_tile = (flags & 0x40) ? 2 : 1;
+    if (flags >> 8) g_min_blocks = flags >> 8;
+    return 0;
+}
 
 int ds6g_conv2d_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int K, int R,
                     int S, int stride, int pad, void* stream) {
