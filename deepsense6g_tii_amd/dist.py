@@ -25,6 +25,11 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (one-GPU box): DS6G_DIST_BACKEND=gloo and DS6G_FORCE_DEVICE=0 let two ranks share a card;
+    # RCCL itself refuses two ranks on one GPU, so production never sets them
+    backend = os.environ.get("DS6G_DIST_BACKEND", backend)
+    if "DS6G_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["DS6G_FORCE_DEVICE"])
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
