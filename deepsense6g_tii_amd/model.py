@@ -204,7 +204,10 @@ class TransFuser(nn.Module):
             self.load_pretrained_weight()
         self._seed = 0x5DEECE66D
         self._drop_counter = 0
-        self._ws = None
+        self._ws_main = None
+        self._ws_side = {}
+        self._side_streams = None
+        self.multi_stream = True  # run the three (independent) trunks on three HIP streams between fusion points
         self._anchor = None
         self._arena = None
         if self.device.type == "cuda":
@@ -266,9 +269,41 @@ class TransFuser(nn.Module):
         self._nbt = torch.zeros(len(nb), dtype=torch.long, device=dev)
         for i, b in enumerate(nb):
             b.data = self._nbt[i]
-        self._ws = ops.Workspace(dev, 1 << 30)
+        self._ws_main = ops.Workspace(dev, 1 << 30)
         self._anchor = torch.zeros(1, dtype=F32, device=dev, requires_grad=True)
         self._pname = {id(p): n for n, p in named}
+
+    @property
+    def _ws(self):
+        """scratch of the stream the caller is launching on (a scratch buffer is only safe within one stream)"""
+        if self._side_streams is not None:
+            ws = self._ws_side.get(torch.cuda.current_stream().cuda_stream)
+            if ws is not None:
+                return ws
+        return self._ws_main
+
+    def _fork(self):
+        """-> the three trunk streams, each ordered after everything enqueued so far on the current stream.
+        Discipline that keeps the caching allocator safe without record_stream(): between _fork() and _join() the
+        calling stream launches nothing, every tensor a trunk stream allocates is used on that stream only until
+        the join, and tensors crossing the boundary are kept alive by the tape."""
+        if self._side_streams is None:
+            self._side_streams = [torch.cuda.Stream(self.device) for _ in range(3)]
+            for st in self._side_streams:
+                self._ws_side[st.cuda_stream] = ops.Workspace(self.device, 256 << 20)
+        cur = torch.cuda.current_stream()
+        for st in self._side_streams:
+            st.wait_stream(cur)
+        return self._side_streams
+
+    def _join(self):
+        cur = torch.cuda.current_stream()
+        for st in self._side_streams:
+            cur.wait_stream(st)
+
+    def _trunk_ctx(self, streams, m):
+        import contextlib
+        return torch.cuda.stream(streams[m]) if streams is not None else contextlib.nullcontext()
 
     def _apply(self, fn, recurse=True):
         # .to(same device) keeps the arena views; a real move would silently detach parameters from it
@@ -510,8 +545,10 @@ class TransFuser(nn.Module):
             self._nbt.add_(1)
         trunks = self._trunks()
         feats, stem_ctx = [], []
-        for (trunk, arch, cin, norm), frames in zip(trunks, (images, lidars, radars)):
-            f, c = self._stem_fwd(trunk, cin, norm, frames, train)
+        streams = self._fork() if self.multi_stream else None
+        for m, ((trunk, arch, cin, norm), frames) in enumerate(zip(trunks, (images, lidars, radars))):
+            with self._trunk_ctx(streams, m):
+                f, c = self._stem_fwd(trunk, cin, norm, frames, train)
             feats.append(f)
             stem_ctx.append(c)
         cap = getattr(self, "_capture", None)  # test hook: name -> list of NHWC / token tensors
@@ -522,14 +559,19 @@ class TransFuser(nn.Module):
         xo = None
         for s in range(1, 5):
             lc = []
+            if streams is not None and s > 1:
+                self._fork()
             for m, (trunk, arch, cin, norm) in enumerate(trunks):
                 bc = []
                 x = feats[m]
-                for blk in getattr(trunk, f"layer{s}"):
-                    x, c = self._block_fwd(blk, x, train)
-                    bc.append(c)
+                with self._trunk_ctx(streams, m):
+                    for blk in getattr(trunk, f"layer{s}"):
+                        x, c = self._block_fwd(blk, x, train)
+                        bc.append(c)
                 feats[m] = x
                 lc.append(bc)
+            if streams is not None:
+                self._join()
             layer_ctx.append(lc)
             if cap is not None:
                 cap[f"layer{s}"] = [f.clone() for f in feats]
@@ -679,6 +721,19 @@ class TransFuser(nn.Module):
                            2 * B, 0, 0, aw, st)
         return dfeats, dprev
 
+    def _stem_bwd(self, trunk, ctx, dpool, cin):
+        L = lib()
+        st = ops._stream()
+        x, c1, a1, st1, idx, _ = ctx
+        N, H1, W1, _ = a1.shape
+        da1 = torch.empty_like(a1)
+        L.maxpool3x3s2_bwd(dpool.data_ptr(), idx.data_ptr(), da1.data_ptr(), N, H1, W1, 64, st)
+        dc1, _ = self._bn_bwd(trunk.bn1, da1, a1, c1, st1)
+        dwpad = torch.empty((64, 7, 7, 4), dtype=F32, device=self.device)
+        ops.conv2d_wgrad(x, dc1, dwpad.data_ptr(), 7, 7, 2, 3, self._ws)
+        gw, aw = self._g(trunk.conv1.weight)
+        L.pad_channels(dwpad.data_ptr(), gw, 64 * 49, cin, 4, 1, aw, st)
+
     def _run_backward(self, tape, dlogits):
         L = lib()
         st = ops._stream()
@@ -715,22 +770,18 @@ class TransFuser(nn.Module):
             dfeats, dprev = self._stage_bwd(stage_ctx[s - 1], dfeats, dgps, B)
             self._milestone_done(1 + 2 * (4 - s))
             dgps = (dprev, False)
+            streams = self._fork() if self.multi_stream else None
             for m, (trunk, arch, cin, norm) in enumerate(trunks):
                 blocks = list(getattr(trunk, f"layer{s}"))
                 d = dfeats[m]
-                for blk, bc in zip(reversed(blocks), reversed(layer_ctx[s - 1][m])):
-                    d = self._block_bwd(blk, bc, d)
+                with self._trunk_ctx(streams, m):
+                    for blk, bc in zip(reversed(blocks), reversed(layer_ctx[s - 1][m])):
+                        d = self._block_bwd(blk, bc, d)
+                    if s == 1:  # the stem backward continues on the same trunk stream
+                        self._stem_bwd(trunk, stem_ctx[m], d, cin)
                 dfeats[m] = d
+            if streams is not None:
+                self._join()
             self._milestone_done(2 + 2 * (4 - s))
-        for m, (trunk, arch, cin, norm) in enumerate(trunks):
-            x, c1, a1, st1, idx, _ = stem_ctx[m]
-            N, H1, W1, _ = a1.shape
-            da1 = torch.empty_like(a1)
-            L.maxpool3x3s2_bwd(dfeats[m].data_ptr(), idx.data_ptr(), da1.data_ptr(), N, H1, W1, 64, st)
-            dc1, _ = self._bn_bwd(trunk.bn1, da1, a1, c1, st1)
-            dwpad = torch.empty((64, 7, 7, 4), dtype=F32, device=self.device)
-            ops.conv2d_wgrad(x, dc1, dwpad.data_ptr(), 7, 7, 2, 3, self._ws)
-            gw, aw = self._g(trunk.conv1.weight)
-            L.pad_channels(dwpad.data_ptr(), gw, 64 * 49, cin, 4, 1, aw, st)
         self._milestone_done(9)
         self._end_backward()

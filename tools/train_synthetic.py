@@ -1,0 +1,56 @@
+"""Train the HIP path on the synthetic *learnable* beam task and report held-out DBA / top-k (GPU box).
+Mirrors the loop of Engine.train / Engine.validate (train2_seq.py:94-221): AdamW, focal loss on soft targets,
+EMA shadow weights for evaluation, per-'epoch' cyclic-cosine LR."""
+import argparse, os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from deepsense6g_tii_amd.model import GlobalConfig, TransFuser
+from deepsense6g_tii_amd.synthetic import make_batch
+from deepsense6g_tii_amd.train import EMA, FusedAdamW, CyclicCosineDecayLR, train_iteration, compute_acc, compute_DBA_score
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--batch", type=int, default=12)
+ap.add_argument("--lr", type=float, default=1e-4)
+ap.add_argument("--pool", type=int, default=16, help="distinct training batches (seeds)")
+ap.add_argument("--eval-batches", type=int, default=8)
+ap.add_argument("--ema", type=int, default=0)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+torch.manual_seed(100)
+cfg = GlobalConfig()
+model = TransFuser(cfg, dev)
+opt = FusedAdamW(model, lr=args.lr, ema_decay=0.999 if args.ema else None)
+ema = None
+if args.ema:
+    ema = EMA(model, 0.999, opt); ema.register()
+
+def evaluate():
+    if ema: ema.apply_shadow()
+    model.eval()
+    preds, truth = [], []
+    with torch.no_grad():
+        for i in range(args.eval_batches):
+            f, l, r, g, t, beam = make_batch(args.batch, seed=10_000 + i, device=dev, learnable=True)  # disjoint seeds
+            logits = model(f, l, r, g)
+            preds.append(torch.argsort(logits, dim=1, descending=True).cpu().numpy())
+            truth.append(beam.numpy())
+    if ema: ema.restore()
+    p, y = np.concatenate(preds), np.concatenate(truth)
+    return compute_DBA_score(p, y), compute_acc(p, y)
+
+pool = [make_batch(args.batch, seed=100 + i, device=dev, learnable=True) for i in range(args.pool)]
+dba0, acc0 = evaluate()
+print(json.dumps(dict(step=0, dba=dba0, top123=acc0.tolist())), flush=True)
+model.train()
+t0 = time.time()
+for step in range(1, args.steps + 1):
+    f, l, r, g, t, _ = pool[step % args.pool]
+    loss, _ = train_iteration(model, opt, (f, l, r, g, t), ema)
+    if step % 50 == 0 or step == args.steps:
+        torch.cuda.synchronize()
+        dba, acc = evaluate()
+        model.train()
+        print(json.dumps(dict(step=step, loss=float(loss), dba=dba, top123=acc.tolist(),
+                              samples_per_s=step * args.batch / (time.time() - t0))), flush=True)
