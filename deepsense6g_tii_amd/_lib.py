@@ -18,7 +18,7 @@ import torch  # noqa: F401
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG_DIR)
 HEADER = os.path.join(_ROOT, "include", "ds6g.h")
-LIB_PATH = os.path.join(_PKG_DIR, "libds6g.so")
+LIB_PATH = os.environ.get("DS6G_LIB", os.path.join(_PKG_DIR, "libds6g.so"))  # DS6G_LIB: A/B a second build
 
 _CTYPES = {
     "int": ctypes.c_int,
