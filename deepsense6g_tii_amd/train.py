@@ -206,6 +206,40 @@ def compute_DBA_score(y_pred, y_true, max_k=3, delta=5):
     return float(np.mean(yk))
 
 
+def strip_module_prefix(state_dict):
+    """Checkpoints written through DataParallel carry a 'module.' prefix (train2_seq.py:276-289, my_test.py:11-22)."""
+    return {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+
+
+@torch.no_grad()
+def validate(model, batches, ema=None):
+    """Engine.validate (train2_seq.py:158-221): optional EMA shadow swap -> eval-mode forward (running BN stats,
+    no dropout) -> argsort -> top-k accuracy and DBA -> restore.  batches: iterable of
+    (fronts, lidars, radars, gps, beamidx).  Returns (DBA, top-1/2/3 accuracy [%], argsorted predictions)."""
+    if ema is not None:
+        ema.apply_shadow()
+    was_training = model.training
+    model.eval()
+    preds, truth = [], []
+    for fronts, lidars, radars, gps, beamidx in batches:
+        logits = model(fronts, lidars, radars, gps)
+        preds.append(torch.argsort(logits, dim=1, descending=True).cpu().numpy())
+        truth.append(np.asarray(beamidx.cpu() if torch.is_tensor(beamidx) else beamidx))
+    model.train(was_training)
+    if ema is not None:
+        ema.restore()
+    p, y = np.concatenate(preds), np.concatenate(truth)
+    return compute_DBA_score(p, y), compute_acc(p, y), p
+
+
+def save_pred_to_csv(y_pred, top_k=(1, 2, 3), target_csv="beam_pred.csv"):
+    """train2_seq.py:338-346: 1-based top-k beams, one row per sample (plain csv, no pandas needed)."""
+    with open(target_csv, "w") as f:
+        f.write("index," + ",".join(f"top-{k} beam" for k in top_k) + "\n")
+        for i, row in enumerate(np.asarray(y_pred)):
+            f.write(f"{i}," + ",".join(str(int(row[k - 1]) + 1) for k in top_k) + "\n")
+
+
 def train_iteration(model, optimizer, batch, ema=None, reducer=None):
     """One iteration in the order of Engine.train (train2_seq.py:106-134) on the fused harness path.
     batch = (fronts, lidars, radars, gps, soft_target).  Returns (loss [1], logits)."""

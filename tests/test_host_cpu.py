@@ -156,3 +156,14 @@ def test_data_parallel_allreduce_world2_gloo():
     assert issued0 == issued1 == [(0, 350), (350, 900), (900, 1000)]  # coalesced to >= 300-element buckets
     assert torch.equal(p0, torch.zeros(16)) and torch.equal(p1, torch.zeros(16))
     assert torch.equal(b1, torch.zeros(4))
+
+
+def test_checkpoint_prefix_and_csv(tmp_path):
+    sd = {"module.join.0.weight": 1, "encoder.vel_emb1.bias": 2}
+    assert T.strip_module_prefix(sd) == {"join.0.weight": 1, "encoder.vel_emb1.bias": 2}
+    pred = np.array([[4, 3, 50] + [0] * 61, [63, 0, 1] + [0] * 61])
+    out = tmp_path / "beam_pred.csv"
+    T.save_pred_to_csv(pred, target_csv=str(out))
+    lines = out.read_text().strip().split("\n")
+    assert lines[0] == "index,top-1 beam,top-2 beam,top-3 beam"   # train2_seq.py:343-346 (1-based beams)
+    assert lines[1] == "0,5,4,51" and lines[2] == "1,64,1,2"

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 from deepsense6g_tii_amd.model import GlobalConfig, TransFuser
 from deepsense6g_tii_amd.synthetic import make_batch
-from deepsense6g_tii_amd.train import EMA, FusedAdamW, CyclicCosineDecayLR, train_iteration, compute_acc, compute_DBA_score
+from deepsense6g_tii_amd.train import EMA, FusedAdamW, train_iteration, validate
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=200)
@@ -27,18 +27,12 @@ if args.ema:
     ema = EMA(model, 0.999, opt); ema.register()
 
 def evaluate():
-    if ema: ema.apply_shadow()
-    model.eval()
-    preds, truth = [], []
-    with torch.no_grad():
-        for i in range(args.eval_batches):
-            f, l, r, g, t, beam = make_batch(args.batch, seed=10_000 + i, device=dev, learnable=True)  # disjoint seeds
-            logits = model(f, l, r, g)
-            preds.append(torch.argsort(logits, dim=1, descending=True).cpu().numpy())
-            truth.append(beam.numpy())
-    if ema: ema.restore()
-    p, y = np.concatenate(preds), np.concatenate(truth)
-    return compute_DBA_score(p, y), compute_acc(p, y)
+    held_out = []
+    for i in range(args.eval_batches):  # disjoint seed range
+        f, l, r, g, t, beam = make_batch(args.batch, seed=10_000 + i, device=dev, learnable=True)
+        held_out.append((f, l, r, g, beam))
+    dba, acc, _ = validate(model, held_out, ema)
+    return dba, acc
 
 pool = [make_batch(args.batch, seed=100 + i, device=dev, learnable=True) for i in range(args.pool)]
 dba0, acc0 = evaluate()
