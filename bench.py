@@ -13,7 +13,9 @@ sequence, bs=12 per GPU); configs[1] ("image-only") is the same compute with zer
 Prints ONE JSON line on rank 0 with the contract fields plus
   roofline     : dominant kernel = the implicit-GEMM instantiation with the largest share of step time;
                  achieved = algorithmic FLOPs of its launches / their HIP-event time, measured live in one
-                 extra instrumented step on the launch stream; peak = 157.3 TFLOP/s (fp32 MFMA, gfx950)
+                 extra instrumented step (single stream, so brackets are not inflated by the concurrent trunk
+                 streams of the timed region); peak = 157.3 TFLOP/s (fp32 MFMA, gfx950); traffic = HBM bytes per
+                 launch from the committed PMC passes (profiles/r01_pmc_traffic.json)
   cpu_baseline : the CPU oracle (oracle/, torch fp32 on the host cores) timed on a bounded sample.
 """
 from __future__ import annotations
@@ -138,6 +140,8 @@ def main():
     ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (sequences)")
     ap.add_argument("--ema", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="run the three trunks on one stream (per-kernel profiling: durations are not overlapped)")
     ap.add_argument("--cpu-batch", type=int, default=12)
     ap.add_argument("--cpu-steps", type=int, default=2)
     args = ap.parse_args()
@@ -156,6 +160,7 @@ def main():
     torch.manual_seed(100)  # reference seeds everything with 100 (train2_seq.py:430-437)
     model = TransFuser(cfg, dev)
     model.train()
+    model.multi_stream = not args.single_stream
     opt = FusedAdamW(model, lr=1e-4, ema_decay=0.999 if args.ema else None)
     ema = None
     if args.ema:
@@ -192,11 +197,28 @@ def main():
     roof = None
     timer = IgemmTimer()
     timer.install()
+    ms_flag = model.multi_stream
+    model.multi_stream = False  # kernels of concurrent trunk streams would inflate each other's event brackets
     try:
         train_iteration(model, opt, batch, ema, reducer)
         agg = timer.summary()
     finally:
         timer.uninstall()
+        model.multi_stream = ms_flag
+    def pmc_traffic(variant):
+        """HBM bytes per launch of an igemm instantiation from the committed rocprofv3 PMC passes (profiles/):
+        FETCH_SIZE and WRITE_SIZE are collected in separate runs of this same command, so bench.py cannot measure
+        them live; null when the summary is absent."""
+        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if not os.path.exists(path):
+            return None
+        ks = json.load(open(path))["kernels"]
+        bm, bn = VARIANT_NAMES[variant % 10].split("x")
+        pref = f"igemm_kernel<{variant // 10}, {bm}, {bn}, "
+        sel = [v for k, v in ks.items() if k.startswith(pref)]
+        n = sum(v["launches"] for v in sel)
+        return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n if n else None
+
     if agg:
         dom = max(agg, key=lambda v: agg[v][2])
         cnt, fl, ms = agg[dom]
@@ -204,7 +226,7 @@ def main():
         tot_fl = sum(v[1] for v in agg.values())
         roof = dict(bound="mfma", kernel=f"igemm_kernel<{MODE_NAMES[dom // 10]},{VARIANT_NAMES[dom % 10]}>",
                     achieved=fl / (ms * 1e-3) / 1e12, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, traffic=None,
+                    frac=fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, traffic=pmc_traffic(dom),
                     launches_per_step=cnt, avg_launch_us=ms * 1e3 / cnt, flops_per_launch=fl / cnt,
                     igemm_family=dict(achieved=tot_fl / (tot_ms * 1e-3) / 1e12, ms_per_step=tot_ms,
                                       flops_per_step=tot_fl,

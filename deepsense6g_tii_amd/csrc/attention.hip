@@ -184,7 +184,20 @@ __device__ __forceinline__ void store_rows(const f32x16* acc, float* base, int l
     const int tid = threadIdx.x, lane = tid & 63;                                                      \
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                         \
     const int l31 = lane & 31, half = lane >> 5;                                                       \
-    const int h = blockIdx.y % p.nh, split = blockIdx.y / p.nh, b = blockIdx.z;                        \
+    /* XCD-aware order: the hardware deals consecutive workgroups round-robin over the 8 XCDs (private L2s); \
+       remap so that the workgroups sharing one (batch, head)'s K/V (or Q/dO) tiles run on ONE XCD and hit its  \
+       L2 instead of each re-fetching them (measured: 5.7x the algorithmic bytes without this). */            \
+    int bx_, by_, bz_;                                                                                 \
+    {                                                                                                  \
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;                                             \
+        const int orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);               \
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;                                         \
+        const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);    \
+        bx_ = wg % gridDim.x;                                                                          \
+        by_ = (wg / gridDim.x) % gridDim.y;                                                            \
+        bz_ = wg / (gridDim.x * gridDim.y);                                                            \
+    }                                                                                                  \
+    const int h = by_ % p.nh, split = by_ / p.nh, b = bz_;                                             \
     const int T = p.T;                                                                                 \
     const long head_off = (long)b * T * p.ld + h * HD;                                                 \
     const int ntiles = (T + 31) / 32;                                                                  \
@@ -198,7 +211,7 @@ __device__ __forceinline__ void store_rows(const f32x16* acc, float* base, int l
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     ATTN_COMMON();
-    const int q_row = blockIdx.x * 128 + wave * 32 + l31;
+    const int q_row = bx_ * 128 + wave * 32 + l31;
     const i32x4 k_srd = make_srd(p.k, p.bytes), v_srd = make_srd(p.v, p.bytes);
 
     float qreg[HD / 2];
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(const float* __rest
 template <int HD>
 __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(const AttnParams p) {
     ATTN_COMMON();
-    const int q_row = blockIdx.x * 128 + wave * 32 + l31;
+    const int q_row = bx_ * 128 + wave * 32 + l31;
     const bool q_ok = q_row < T;
     const i32x4 k_srd = make_srd(p.k, p.bytes), v_srd = make_srd(p.v, p.bytes);
 
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
     ATTN_COMMON();
     __shared__ float lse_s[2][32];
     __shared__ float delta_s[2][32];
-    const int key = blockIdx.x * 128 + wave * 32 + l31;
+    const int key = bx_ * 128 + wave * 32 + l31;
     const bool key_ok = key < T;
     const i32x4 q_srd = make_srd(p.q, p.bytes), do_srd = make_srd(p.d_o, p.bytes);
 
