@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (no 2:1 sparsity)
 VARIANT_NAMES = {0: "128x128", 1: "128x64", 2: "64x64"}
 MODE_NAMES = {0: "fwd", 1: "dgrad", 2: "wgrad"}
 
@@ -140,6 +141,9 @@ def main():
     ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (sequences)")
     ap.add_argument("--ema", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="matrix-core mode: f32 = exact fp32 MFMA (parity path, default); bf16 = operands rounded to bf16, "
+                         "fp32 accumulate/storage (BASELINE configs[1]-style throughput configuration)")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the three trunks on one stream (per-kernel profiling: durations are not overlapped)")
     ap.add_argument("--cpu-batch", type=int, default=12)
@@ -147,10 +151,13 @@ def main():
     args = ap.parse_args()
 
     from deepsense6g_tii_amd import dist as ddist
+    from deepsense6g_tii_amd import ops
     from deepsense6g_tii_amd.model import GlobalConfig, TransFuser
     from deepsense6g_tii_amd.synthetic import make_batch
     from deepsense6g_tii_amd.train import EMA, FusedAdamW, train_iteration
 
+    ops.set_compute_mode(args.dtype)
+    peak_tflops = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
     rank, world, local = ddist.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
@@ -225,8 +232,8 @@ def main():
         tot_ms = sum(v[2] for v in agg.values())
         tot_fl = sum(v[1] for v in agg.values())
         roof = dict(bound="mfma", kernel=f"igemm_kernel<{MODE_NAMES[dom // 10]},{VARIANT_NAMES[dom % 10]}>",
-                    achieved=fl / (ms * 1e-3) / 1e12, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, traffic=pmc_traffic(dom),
+                    achieved=fl / (ms * 1e-3) / 1e12, peak=peak_tflops, unit="TFLOP/s",
+                    frac=fl / (ms * 1e-3) / 1e12 / peak_tflops, traffic=pmc_traffic(dom) if args.dtype == "f32" else None,
                     launches_per_step=cnt, avg_launch_us=ms * 1e3 / cnt, flops_per_launch=fl / cnt,
                     igemm_family=dict(achieved=tot_fl / (tot_ms * 1e-3) / 1e12, ms_per_step=tot_ms,
                                       flops_per_step=tot_fl,
@@ -253,7 +260,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: full camera+LiDAR+radar+GPS fusion, 5x(3+1+2)x256x256 + 2x2 "
                                    "GPS per sample, bs=12 per GPU, sigmoid focal loss, AdamW, train-mode BN, dropout 0.1",

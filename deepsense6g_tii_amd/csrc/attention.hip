@@ -122,9 +122,25 @@ __device__ __forceinline__ void load_frag(float* reg, const float* base, long ro
 }
 
 // acc += A . B^T over the head dim: A rows come from the LDS tile (row = lane&31), B from registers
-template <int HD>
+template <int HD, int BF>
 __device__ __forceinline__ void mma_rows(f32x16& acc, unsigned tile, const float* breg, int l31, int half) {
     constexpr int NCH = HD / 8;  // 16-B chunks per lane half
+    if (BF) {  // bf16 matrix cores: 16 head dims per MFMA (lane half h supplies dims h*HD/2 + 8c .. +7 of chunk c)
+#pragma unroll
+        for (int c = 0; c < HD / 16; ++c) {
+            const f32x4 v0 = row_read<HD>(tile, l31, half * NCH + 2 * c), v1 = row_read<HD>(tile, l31, half * NCH + 2 * c + 1);
+            bf16x8 a8, b8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a8[e] = (__bf16)v0[e];
+                a8[4 + e] = (__bf16)v1[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b8[e] = (__bf16)breg[8 * c + e];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc, 0, 0, 0);
+        }
+        return;
+    }
     f32x4 cur = row_read<HD>(tile, l31, half * NCH);
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -136,9 +152,25 @@ __device__ __forceinline__ void mma_rows(f32x16& acc, unsigned tile, const float
 }
 
 // acc[blk] (X^T[d][col-on-lane]) += sum_r tile[krow16(r,half)][d] * p[r]
-template <int HD>
+template <int HD, int BF>
 __device__ __forceinline__ void mma_dims(f32x16* acc, unsigned tile, const f32x16& p, const unsigned* dtab) {
     constexpr int NB = (HD + 31) / 32;
+    if (BF) {  // accumulator registers 8s..8s+7 are exactly the bf16 operand fragment of k-step s (key order krow16)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 b8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b8[e] = (__bf16)p[8 * s2 + e];
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                bf16x8 a8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a8[e] = (__bf16)dim_read<HD>(tile, dtab, 8 * s2 + e, blk);
+                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[blk], 0, 0, 0);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
 #pragma unroll
@@ -208,7 +240,7 @@ __device__ __forceinline__ void store_rows(const f32x16* acc, float* base, int l
     (void)NB;
 
 // ------------------------------------------------------------------------------------------------
-template <int HD>
+template <int HD, int BF>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     ATTN_COMMON();
     const int q_row = bx_ * 128 + wave * 32 + l31;
@@ -233,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        mma_rows<HD>(s, Kc, qreg, l31, half);
+        mma_rows<HD, BF>(s, Kc, qreg, l31, half);
         const int key0 = kt * 32;
         float mloc = -INFINITY;
 #pragma unroll
@@ -263,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 s[r] = ds6g_keep(p.seed, p.seed_off + (uint64_t)(drop_row + key), p.thr) ? s[r] * p.dscale : 0.f;
             }
         }
-        mma_dims<HD>(oacc, Vc, s, dtab);
+        mma_dims<HD, BF>(oacc, Vc, s, dtab);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -323,7 +355,7 @@ __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(const float* __rest
 
 // ------------------------------------------------------------------------------------------------
 // dQ (and delta): one wave = 32 queries, loop over (a split of) the key tiles
-template <int HD>
+template <int HD, int BF>
 __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(const AttnParams p) {
     ATTN_COMMON();
     const int q_row = bx_ * 128 + wave * 32 + l31;
@@ -364,8 +396,8 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-        mma_rows<HD>(s, Kc, qreg, l31, half);
-        mma_rows<HD>(dp, Vc, doreg, l31, half);
+        mma_rows<HD, BF>(s, Kc, qreg, l31, half);
+        mma_rows<HD, BF>(dp, Vc, doreg, l31, half);
         const int key0 = kt * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -375,7 +407,7 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
             if (p.thr) g = ds6g_keep(p.seed, p.seed_off + (uint64_t)(drop_row + key), p.thr) ? g * p.dscale : 0.f;
             s[r] = pr * (g - delta) * p.scale;  // dS (scaled)
         }
-        mma_dims<HD>(dq, Kc, s, dtab);
+        mma_dims<HD, BF>(dq, Kc, s, dtab);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -397,7 +429,7 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
 // dK, dV: one wave = 32 keys (key on the lane), loop over (a split of) the query tiles.
 // PART 0 = both (4 products per tile); 1 = dV only (S, dV); 2 = dK only (S, dP, dK).  At HD = 128 the fused form
 // needs > 512 registers (K, V fragments + two accumulator sets), so it runs as PART 1 + PART 2.
-template <int HD, int PART>
+template <int HD, int PART, int BF>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
     constexpr bool DO_DV = PART != 2, DO_DK = PART != 1;
     ATTN_COMMON();
@@ -438,9 +470,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-        mma_rows<HD>(s, Qc, kreg, l31, half);
+        mma_rows<HD, BF>(s, Qc, kreg, l31, half);
         __builtin_amdgcn_sched_barrier(0);
-        if (DO_DK) mma_rows<HD>(dp, Oc, vreg, l31, half);
+        if (DO_DK) mma_rows<HD, BF>(dp, Oc, vreg, l31, half);
         __builtin_amdgcn_sched_barrier(0);
         const int q0 = qt * 32;
 #pragma unroll
@@ -459,9 +491,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
             s[r] = pr;  // dropped probabilities
         }
         __builtin_amdgcn_sched_barrier(0);  // phase fences keep the LDS-read prefetch of one product from
-        if (DO_DV) mma_dims<HD>(dv, Oc, s, dtab);  // overlapping the live registers of the next
+        if (DO_DV) mma_dims<HD, BF>(dv, Oc, s, dtab);  // overlapping the live registers of the next
         __builtin_amdgcn_sched_barrier(0);
-        if (DO_DK) mma_dims<HD>(dk, Qc, dp, dtab);
+        if (DO_DK) mma_dims<HD, BF>(dk, Qc, dp, dtab);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -507,18 +539,18 @@ int pick_splits(long base_blocks, int ntiles, int per_cu, int max_splits) {
     return best;
 }
 
-template <int KIND>
-int launch_hd(const AttnParams& p, int hd, dim3 grid, hipStream_t st) {
+template <int KIND, int BF>
+int launch_hd_bf(const AttnParams& p, int hd, dim3 grid, hipStream_t st) {
 #define ATTN_CASE(HDV)                                                                                        \
     case HDV:                                                                                                 \
-        if (KIND == 0) hipLaunchKernelGGL((attn_fwd_kernel<HDV>), grid, dim3(256), 0, st, p);                 \
-        if (KIND == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<HDV>), grid, dim3(256), 0, st, p);              \
+        if (KIND == 0) hipLaunchKernelGGL((attn_fwd_kernel<HDV, BF>), grid, dim3(256), 0, st, p);             \
+        if (KIND == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<HDV, BF>), grid, dim3(256), 0, st, p);          \
         if (KIND == 2) {                                                                                      \
             if (HDV >= 128) {                                                                                 \
-                hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 1>), grid, dim3(256), 0, st, p);                 \
-                hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 2>), grid, dim3(256), 0, st, p);                 \
+                hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 1, BF>), grid, dim3(256), 0, st, p);             \
+                hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 2, BF>), grid, dim3(256), 0, st, p);             \
             } else {                                                                                          \
-                hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 0>), grid, dim3(256), 0, st, p);                 \
+                hipLaunchKernelGGL((attn_bwd_dkv_kernel<(HDV >= 128 ? 64 : HDV), 0, BF>), grid, dim3(256), 0, st, p); \
             }                                                                                                 \
         }                                                                                                     \
         break;
@@ -534,6 +566,11 @@ int launch_hd(const AttnParams& p, int hd, dim3 grid, hipStream_t st) {
 #undef ATTN_CASE
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
+}
+
+template <int KIND>
+int launch_hd(const AttnParams& p, int hd, dim3 grid, hipStream_t st) {
+    return g_ds6g_bf16 ? launch_hd_bf<KIND, 1>(p, hd, grid, st) : launch_hd_bf<KIND, 0>(p, hd, grid, st);
 }
 
 }  // namespace

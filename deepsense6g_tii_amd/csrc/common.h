@@ -34,6 +34,12 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifdef __HIPCC__
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#endif
+
+// process-wide matrix-core mode (ds6g_set_compute_mode): 0 = exact fp32 MFMA, 1 = bf16 operands / fp32 accumulate
+extern int g_ds6g_bf16;
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

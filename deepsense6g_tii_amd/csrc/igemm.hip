@@ -56,7 +56,10 @@ struct IgemmParams {
 
 // EPI 0: store (or accumulate) only - branch-free bounds handling through a buffer descriptor;
 // EPI 1: full epilogue (bias, ReLU, ReLU-mask, dropout, residual, accumulate, strided-dgrad row remap).
-template <int MODE, int BM, int BN, int EPI, int BK>
+// BF 1: operands are rounded to bf16 (RNE) on the way from the LDS fragment to the matrix core and one
+// v_mfma_f32_32x32x16_bf16 replaces the eight fp32 MFMAs of a k-tile (fp32 accumulate, fp32 storage everywhere):
+// the "bf16 forward/backward" throughput configuration of BASELINE.json; BF 0 is the exact-fp32 parity path.
+template <int MODE, int BM, int BN, int EPI, int BK, int BF>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int CH = BK / 4;              // 16-B chunks per K-contiguous row
     constexpr int RPB = 16 / CH;            // rows per 256-B LDS bank row
@@ -316,13 +319,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         // keep every fragment read ahead of the MFMA chain (the scheduler otherwise sinks each read next to
         // its use and exposes the LDS latency once per k-step)
         __builtin_amdgcn_sched_barrier(0);
+        if (BF) {
+            static_assert(!BF || BK == 16, "one 32x32x16 bf16 MFMA per k-tile: lane half h holds k = 8h..8h+7");
+            bf16x8 a8[TM], b8[TN];
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a8[i][e] = (__bf16)af[i][e];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b8[j][e] = (__bf16)bf[j][e];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+            }
         }
         // the DMA of the next tile must have landed before any wave reads it, and every wave must be done reading
         // the current buffers before the DMA after next overwrites them.  sched_barrier pins the wait BEHIND the
@@ -443,21 +464,21 @@ int pick_tile(int Mg, int Ng, long splits) {
     return 2;
 }
 
-template <int MODE, int EPI, int BKV>
+template <int MODE, int EPI, int BKV, int BF>
 void launch_tile(IgemmParams& p, int splits, int tile, hipStream_t st) {
     dim3 block(256);
     if (tile == 0) {
         p.tiles_n = cdiv(p.Ng, 128);
         dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, 1, splits);
-        hipLaunchKernelGGL((igemm_kernel<MODE, 128, 128, EPI, BKV>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((igemm_kernel<MODE, 128, 128, EPI, BKV, BF>), grid, block, 0, st, p);
     } else if (tile == 1) {
         p.tiles_n = cdiv(p.Ng, 64);
         dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, 1, splits);
-        hipLaunchKernelGGL((igemm_kernel<MODE, 128, 64, EPI, BKV>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((igemm_kernel<MODE, 128, 64, EPI, BKV, BF>), grid, block, 0, st, p);
     } else {
         p.tiles_n = cdiv(p.Ng, 64);
         dim3 grid(cdiv(p.Mg, 64) * p.tiles_n, 1, splits);
-        hipLaunchKernelGGL((igemm_kernel<MODE, 64, 64, EPI, BKV>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((igemm_kernel<MODE, 64, 64, EPI, BKV, BF>), grid, block, 0, st, p);
     }
 }
 
@@ -467,8 +488,13 @@ int launch_igemm(IgemmParams& p, int splits, int tile, hipStream_t st) {
     const bool full = p.bias || p.relu || p.mask_src || p.drop_thr || p.residual || (MODE == MODE_DGRAD && p.hstep != 1);
     if ((size_t)p.Mg * p.Ng * sizeof(float) >= OOB_OFF) return DS6G_ERR_ARG;
     // BK = 32 was measured (tools/bench_igemm.py): within +-5 % on fwd/dgrad, 10-30 % slower on wgrad -> BK = 16
-    if (MODE != MODE_WGRAD && full) launch_tile<MODE, 1, 16>(p, splits, tile, st);
-    else launch_tile<MODE, 0, 16>(p, splits, tile, st);
+    if (g_ds6g_bf16) {
+        if (MODE != MODE_WGRAD && full) launch_tile<MODE, 1, 16, 1>(p, splits, tile, st);
+        else launch_tile<MODE, 0, 16, 1>(p, splits, tile, st);
+    } else {
+        if (MODE != MODE_WGRAD && full) launch_tile<MODE, 1, 16, 0>(p, splits, tile, st);
+        else launch_tile<MODE, 0, 16, 0>(p, splits, tile, st);
+    }
     g_last_variant = MODE * 10 + tile;
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;

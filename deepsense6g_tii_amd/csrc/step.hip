@@ -6,6 +6,8 @@
 // 16-B accesses; algorithmic traffic 28 B/param (+12 B/param with EMA).
 #include "common.h"
 
+int g_ds6g_bf16 = 0;
+
 namespace {
 
 // loss = mean_i ce_i (1-p_t)^gamma (alpha t + (1-alpha)(1-t));  dlogits_i = dloss/dx_i * upstream
@@ -186,5 +188,11 @@ int ds6g_small_linear_bwd(const float* dy, const float* y_mask, const float* x, 
 }
 
 int ds6g_version(void) { return 1; }
+
+int ds6g_set_compute_mode(int bf16_matrix_cores) {
+    g_ds6g_bf16 = bf16_matrix_cores ? 1 : 0;
+    return 0;
+}
+int ds6g_get_compute_mode(void) { return g_ds6g_bf16; }
 
 }  // extern "C"

@@ -210,3 +210,17 @@ def axpby(a, b, alpha=1.0, beta=1.0, out=None):
     o = out if out is not None else torch.empty_like(a)
     lib().axpby(_p(a), _p(b), _p(o), a.numel(), float(alpha), float(beta), _stream())
     return o
+
+
+def set_compute_mode(mode: str):
+    """Process-wide matrix-core mode of the GEMM-shaped kernels (ds6g_set_compute_mode):
+    "f32"  - exact fp32 MFMA, the parity path (default);
+    "bf16" - operands rounded to bf16 on the way into the MFMA, fp32 accumulate and storage (throughput mode; the
+             reference has no mixed precision, tolerances for it are declared in tests/test_bf16_gpu.py)."""
+    if mode not in ("f32", "bf16"):
+        raise ValueError(f"compute mode must be 'f32' or 'bf16', got {mode!r}")
+    lib().set_compute_mode(1 if mode == "bf16" else 0)
+
+
+def get_compute_mode() -> str:
+    return "bf16" if lib().get_compute_mode() == 1 else "f32"

@@ -28,6 +28,11 @@ int ds6g_version(void);
 int ds6g_last_igemm_variant(void);
 /* ablation switches for kernel timing experiments (results become wrong); 0 = normal operation */
 int ds6g_set_debug_flags(int flags);
+/* matrix-core mode of the conv / linear / attention kernels (process-wide): 0 (default) = exact fp32 MFMA, the parity
+ * path; 1 = operands rounded to bf16 on the way into the matrix cores, fp32 accumulate, fp32 storage (throughput
+ * configuration "bf16 forward/backward" of BASELINE.json).  Everything else (BN, LN, softmax, loss, AdamW) stays fp32. */
+int ds6g_set_compute_mode(int bf16_matrix_cores);
+int ds6g_get_compute_mode(void);
 
 /* ---- igemm.hip : Conv2d / Linear as implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------
  * Conv2d(bias=False) of the ResNet trunks: model2_seq.py:495,500,505 (7x7/2 stems), :510-512,

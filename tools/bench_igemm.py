@@ -23,6 +23,7 @@ LIN = [("bal768", 12288, 1024, 512), ("bal768k4096", 12288, 1024, 4096), ("bal15
 reps = int(os.environ.get("REPS", "5"))
 only = os.environ.get("ONLY")
 lib().set_debug_flags(int(os.environ.get("DBG", "0")))
+lib().set_compute_mode(int(os.environ.get("BF16", "0")))
 
 def timeit(fn):
     fn(); torch.cuda.synchronize()
