@@ -45,6 +45,7 @@ struct IgemmParams {
     int k_per_split;     // multiple of 16
     size_t split_stride; // elements between split-K slabs
     int tiles_n;
+    int is_linear;       // host-side only: the problem is a Linear layer (split-K heuristics)
     int want_colsum;     // WGRAD: also emit column sums of the A operand (bias gradient) behind each slab
     // DGRAD of a strided conv is run per input-pixel parity class: pixels h = h0 + hstep*hh (hh < Hs), taps
     // r = r0 + rstep*ri (ri < nr) - only the taps that hit a real output pixel, no structural zeros
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             } else {
                 off = a_base[i] + (unsigned)a_k[i] * (unsigned)p.K;
             }
+            if (p.dbg & 32) ok = false;
             dma16(a_rsrc, lds_addr(Ad) + (unsigned)(i * 256 + wave * 64) * 16u, ok ? off * 4u : OOB_OFF);
             a_k[i] += BK;
             if (MODE != MODE_WGRAD) {
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                     if (++b_t[i] == p.Ho) { b_t[i] = 0; ++b_n[i]; }
                 }
             }
+            if (p.dbg & 32) ok = false;
             dma16(b_rsrc, lds_addr(Bd) + (unsigned)(i * 256 + wave * 64) * 16u, ok ? off * 4u : OOB_OFF);
             b_k[i] += BK;
         }
@@ -516,7 +519,7 @@ int run_wgrad(IgemmParams& p, float* dw, int accumulate, float* dbias, int accum
     const long tiles = (long)cdiv(p.Mg, tile == 1 ? 128 : 64) * cdiv(p.Ng, 64);
     // measured on gfx950 (tools/bench_igemm.py): convs are fastest with ~2048 workgroups in flight, the GPT
     // linears (large outputs, costlier slab reduction) with ~1024
-    const long target_blocks = (p.R * p.S == 1 && p.H * p.W == 1) ? 1024 : 2048;
+    const long target_blocks = p.is_linear ? 1024 : 2048;
     long splits = (target_blocks + tiles - 1) / tiles;
     const long max_by_k = (p.Kg + 64 - 1) / 64;
     if (splits > max_by_k) splits = max_by_k;
@@ -551,6 +554,13 @@ void fill_conv(IgemmParams& p, int N, int H, int W, int C, int K, int R, int S, 
     p.drop_scale = 1.f;
     p.h0 = 0; p.hstep = 1; p.Hs = H; p.w0 = 0; p.wstep = 1; p.Ws = W;
     p.r0 = 0; p.rstep = 1; p.nr = R; p.s0 = 0; p.sstep = 1; p.ns = S;
+}
+
+// A Linear over M rows is the 1x1 convolution of ONE 1 x M image (not M 1x1 images): the per-k-tile pixel walk of the
+// kernels then never wraps (a wrap costs a VALU loop iteration per crossed image row).
+void fill_linear(IgemmParams& p, int M, int N, int K) {
+    fill_conv(p, 1, 1, M, K, N, 1, 1, 1, 0);
+    p.is_linear = 1;
 }
 
 // byte sizes of the three tensors of a conv (for the buffer descriptors); all must stay below the OOB sentinel
@@ -640,7 +650,7 @@ int ds6g_linear_fwd(const float* x, const float* w, const float* bias, float* y,
     DS6G_ENTER();
     DS6G_CHECK_ARG(x && w && y && K % 4 == 0 && M > 0 && drop_p >= 0.f && drop_p < 1.f);
     IgemmParams p;
-    fill_conv(p, M, 1, 1, K, N, 1, 1, 1, 0);
+    fill_linear(p, M, N, K);
     p.a_src = x; p.b_src = w; p.out = y; p.bias = bias; p.relu = relu; p.residual = residual;
     p.drop_thr = ds6g_drop_threshold(drop_p);
     p.drop_scale = 1.f / (1.f - drop_p);
@@ -658,7 +668,7 @@ int ds6g_linear_dgrad(const float* dy, const float* w, float* dx, int M, int N, 
     DS6G_ENTER();
     DS6G_CHECK_ARG(dy && w && dx && K % 4 == 0 && N % 4 == 0);
     IgemmParams p;
-    fill_conv(p, M, 1, 1, K, N, 1, 1, 1, 0);
+    fill_linear(p, M, N, K);
     p.a_src = dy; p.b_src = w; p.out = dx; p.mask_src = mask_src; p.accumulate = accumulate;
     const ConvBytes cb = conv_bytes(p);
     DS6G_CHECK_ARG(cb.ok);
@@ -673,7 +683,7 @@ int ds6g_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, 
     DS6G_ENTER();
     DS6G_CHECK_ARG(x && dy && dw && K % 4 == 0 && N % 4 == 0);
     IgemmParams p;
-    fill_conv(p, M, 1, 1, K, N, 1, 1, 1, 0);
+    fill_linear(p, M, N, K);
     p.a_src = dy; p.b_src = x;
     const ConvBytes cb = conv_bytes(p);
     DS6G_CHECK_ARG(cb.ok);

@@ -1,0 +1,42 @@
+"""Per-shape breakdown of the implicit-GEMM launches of one bs=12 training step (single stream, HIP events)."""
+import os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from deepsense6g_tii_amd import ops
+from deepsense6g_tii_amd._lib import lib
+from deepsense6g_tii_amd.model import GlobalConfig, TransFuser
+from deepsense6g_tii_amd.synthetic import make_batch
+from deepsense6g_tii_amd.train import FusedAdamW, train_iteration
+
+dev = torch.device("cuda:0")
+ops.set_compute_mode(os.environ.get("DTYPE", "f32"))
+model = TransFuser(GlobalConfig(), dev); model.train(); model.multi_stream = False
+opt = FusedAdamW(model, lr=1e-4)
+batch = make_batch(int(os.environ.get("B", "12")), seed=100, device=dev)[:5]
+for _ in range(2): train_iteration(model, opt, batch)
+torch.cuda.synchronize()
+L = lib(); recs = []
+def wrap(name, key_fn, fl_fn):
+    orig = getattr(L, name)
+    def call(*a):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); orig(*a); e1.record()
+        recs.append((name, key_fn(a), fl_fn(a), L.last_igemm_variant(), e0, e1))
+    setattr(L, name, call)
+def cf(a):
+    N, H, W, C, K, R, S, st, pad = a[3:12]
+    Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - S) // st + 1
+    return 2.0 * N * Ho * Wo * K * R * S * C
+ck = lambda a: tuple(a[3:12])
+wrap("conv2d_fwd", ck, cf); wrap("conv2d_dgrad", ck, cf); wrap("conv2d_wgrad", ck, cf)
+wrap("linear_fwd", lambda a: tuple(a[4:7]), lambda a: 2.0 * a[4] * a[5] * a[6])
+wrap("linear_dgrad", lambda a: tuple(a[3:6]), lambda a: 2.0 * a[3] * a[4] * a[5])
+wrap("linear_wgrad", lambda a: tuple(a[4:7]), lambda a: 2.0 * a[4] * a[5] * a[6])
+train_iteration(model, opt, batch); torch.cuda.synchronize()
+agg = collections.OrderedDict()
+for name, key, fl, var, e0, e1 in recs:
+    d = agg.setdefault((name, key, var), [0, 0.0, 0.0]); d[0] += 1; d[1] += fl; d[2] += e0.elapsed_time(e1)
+tot = sum(d[2] for d in agg.values()); totf = sum(d[1] for d in agg.values())
+print(f"total {tot:.2f} ms  {totf / tot / 1e9:.1f} TF")
+for (name, key, var), (n, fl, ms) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+    print(f"{name:13s} {str(key):44s} v{var:<3d} n={n:3d} {ms:7.3f} ms {ms / n * 1e3:7.1f} us/call {fl / ms / 1e9:6.1f} TF")
