@@ -221,23 +221,28 @@ def main():
             return None
         ks = json.load(open(path))["kernels"]
         bm, bn = VARIANT_NAMES[variant % 10].split("x")
-        pref = f"igemm_kernel<{variant // 10}, {bm}, {bn}, "
+        pref = f"igemm_kernel<{variant % 100 // 10}, {bm}, {bn}, "
         sel = [v for k, v in ks.items() if k.startswith(pref)]
         n = sum(v["launches"] for v in sel)
         return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n if n else None
+
+    def vname(v, short=False):
+        # ds6g_last_igemm_variant(): 100 * uniform-walk + 10 * mode + tile
+        mode, tile, walk = MODE_NAMES[v % 100 // 10], VARIANT_NAMES[v % 10], ("" if v >= 100 else "/general-walk")
+        return f"{mode}/{tile}{walk}" if short else f"igemm_kernel<{mode},{tile}{walk}>"
 
     if agg:
         dom = max(agg, key=lambda v: agg[v][2])
         cnt, fl, ms = agg[dom]
         tot_ms = sum(v[2] for v in agg.values())
         tot_fl = sum(v[1] for v in agg.values())
-        roof = dict(bound="mfma", kernel=f"igemm_kernel<{MODE_NAMES[dom // 10]},{VARIANT_NAMES[dom % 10]}>",
+        roof = dict(bound="mfma", kernel=vname(dom),
                     achieved=fl / (ms * 1e-3) / 1e12, peak=peak_tflops, unit="TFLOP/s",
                     frac=fl / (ms * 1e-3) / 1e12 / peak_tflops, traffic=pmc_traffic(dom) if args.dtype == "f32" else None,
                     launches_per_step=cnt, avg_launch_us=ms * 1e3 / cnt, flops_per_launch=fl / cnt,
                     igemm_family=dict(achieved=tot_fl / (tot_ms * 1e-3) / 1e12, ms_per_step=tot_ms,
                                       flops_per_step=tot_fl,
-                                      by_variant={f"{MODE_NAMES[v // 10]}/{VARIANT_NAMES[v % 10]}":
+                                      by_variant={vname(v, short=True):
                                                   dict(launches=a[0], ms=round(a[2], 3),
                                                        tflops=round(a[1] / (a[2] * 1e-3) / 1e12, 2))
                                                   for v, a in sorted(agg.items())}))

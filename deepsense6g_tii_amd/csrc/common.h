@@ -105,12 +105,14 @@ __device__ __forceinline__ i32x4 make_srd(const void* ptr, unsigned bytes) {
 // drains vmcnt before the fragment reads of the OTHER buffer, which serialises DMA and MFMA.  From asm the
 // compiler does not see the load; its completion is waited for by the explicit `s_waitcnt vmcnt(0)` ahead of
 // the barrier that precedes the reads.  M0 (LDS destination base) is saved/restored inside the statement.
-__device__ __forceinline__ void dma16(const i32x4 srd, unsigned lds_byte_addr, unsigned voffset) {
+// soffset: wave-uniform byte offset added to the address (an SGPR; NOT part of the range check, so an OOB_OFF lane
+// stays out of range whatever soffset is).
+__device__ __forceinline__ void dma16(const i32x4 srd, unsigned lds_byte_addr, unsigned voffset, unsigned soffset = 0u) {
     unsigned keep;
     asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(voffset), "s"(lds_byte_addr), "s"(srd)
+        : "v"(voffset), "s"(lds_byte_addr), "s"(srd), "s"(soffset)
         : "memory");
 }
 

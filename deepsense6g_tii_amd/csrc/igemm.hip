@@ -45,6 +45,7 @@ struct IgemmParams {
     int k_per_split;     // multiple of 16
     size_t split_stride; // elements between split-K slabs
     int tiles_n;
+    int wg_rows;         // FAST WGRAD: 0 = a k-tile of 16 pixels stays inside one output row; else rows per k-tile (16 / Wo)
     int is_linear;       // host-side only: the problem is a Linear layer (split-K heuristics)
     int want_colsum;     // WGRAD: also emit column sums of the A operand (bias gradient) behind each slab
     // DGRAD of a strided conv is run per input-pixel parity class: pixels h = h0 + hstep*hh (hh < Hs), taps
@@ -60,7 +61,12 @@ struct IgemmParams {
 // BF 1: operands are rounded to bf16 (RNE) on the way from the LDS fragment to the matrix core and one
 // v_mfma_f32_32x32x16_bf16 replaces the eight fp32 MFMAs of a k-tile (fp32 accumulate, fp32 storage everywhere):
 // the "bf16 forward/backward" throughput configuration of BASELINE.json; BF 0 is the exact-fp32 parity path.
-template <int MODE, int BM, int BN, int EPI, int BK, int BF>
+// FAST 1: the k walk is wave-uniform - a k-tile never straddles a filter tap (FWD: C % BK == 0, DGRAD: K % BK == 0) or
+// an image row group (WGRAD: see wgrad_fast_ok) - so the per-lane byte offsets are constants of the current tap / of
+// the lane, and the per-k-tile advance lives in SGPRs and rides in the buffer instruction's scalar offset: the loop
+// spends ~2 (FWD/DGRAD) to ~8 (WGRAD) VALU instructions per DMA piece instead of ~25.  FAST 0 is the general walk
+// (any channel count, any image size), kept for the stem (C = 4) and odd shapes.
+template <int MODE, int BM, int BN, int EPI, int BK, int BF, int FAST>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int CH = BK / 4;              // 16-B chunks per K-contiguous row
     constexpr int RPB = 16 / CH;            // rows per 256-B LDS bank row
@@ -193,8 +199,136 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         }
     }
 
+    // ---- FAST walk state: uniform counters (SGPRs) + per-lane constant byte offsets ------------------------------
+    [[maybe_unused]] int u_c0 = 0, u_r = 0, u_s = 0;          // FWD/DGRAD: channel offset inside the tap, tap
+    [[maybe_unused]] unsigned u_kb = 0;                       // FWD: byte offset of the k-tile in a weight row
+    [[maybe_unused]] int u_kpos = kbegin, u_n = 0, u_oh = 0, u_ow = 0;  // WGRAD: first pixel of the k-tile
+    [[maybe_unused]] unsigned a_vo[A_LD], b_vo[B_LD];
+    [[maybe_unused]] int a_kr[A_LD], b_kr[B_LD], b_ihl[B_LD], b_iwl[B_LD];
+    [[maybe_unused]] i32x4 b_rsrc_f = b_rsrc;
+    // FWD/DGRAD: byte offsets of this lane's A pieces for tap (u_r, u_s); OOB_OFF where the tap misses the image
+    auto retap = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            if (MODE == MODE_FWD) {
+                const int ih = a_y[i] + u_r, iw = a_x[i] + u_s;
+                const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                a_vo[i] = ok ? (a_base[i] + (unsigned)((ih * p.W + iw) * p.C + a_c[i])) * 4u : OOB_OFF;
+            } else if (MODE == MODE_DGRAD) {
+                const int th = a_y[i] - (p.r0 + u_r * p.rstep), tw = a_x[i] - (p.s0 + u_s * p.sstep);
+                int oh = th, ow = tw;
+                bool okk = th >= 0 && tw >= 0;
+                if (p.stride == 2) {
+                    oh = th >> 1;
+                    ow = tw >> 1;
+                    okk = okk && !((th | tw) & 1);
+                } else if (p.stride != 1) {
+                    oh = th / p.stride;
+                    ow = tw / p.stride;
+                    okk = okk && (oh * p.stride == th) && (ow * p.stride == tw);
+                }
+                const bool ok = a_ok[i] && okk && oh < p.Ho && ow < p.Wo;
+                a_vo[i] = ok ? (a_base[i] + (unsigned)((oh * p.Wo + ow) * p.K + a_c[i])) * 4u : OOB_OFF;
+            }
+        }
+    };
+    if (FAST) {
+        if (MODE == MODE_FWD) {
+            retap();
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) b_vo[i] = b_ok[i] ? (b_base[i] + (unsigned)b_k[i]) * 4u : OOB_OFF;
+        } else if (MODE == MODE_DGRAD) {
+            retap();
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i)  // k-row (out channel within the tile) of this lane: b_o
+                b_vo[i] = b_ok[i] ? (b_base[i] + (unsigned)(b_o[i] * (p.R * p.S) * p.C)) * 4u : OOB_OFF;
+        } else {
+            // pixel kbegin -> (image, output row, output column); kbegin is a multiple of 32
+            if (p.wg_rows == 0) {
+                u_ow = kbegin % p.Wo;
+                const int t = kbegin / p.Wo;
+                u_oh = t % p.Ho;
+                u_n = t / p.Ho;
+            } else {
+                const int t = kbegin / p.Wo;
+                u_oh = t % p.Ho;
+                u_n = t / p.Ho;
+            }
+            // negative tap offsets (halo) are folded into the descriptor base so that lane constants stay >= 0
+            const int shift = (p.pad * p.W + p.pad) * p.C;
+            b_rsrc_f = make_srd(p.b_src - shift, p.b_bytes + (unsigned)shift * 4u);
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                a_kr[i] = (tid + i * 256) / (BM / 4);
+                a_vo[i] = (a_base[i] + (unsigned)(a_kr[i] * p.K)) * 4u;
+            }
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) {
+                b_kr[i] = (tid + i * 256) / (BN / 4);
+                const int dl_oh = p.wg_rows == 0 ? 0 : b_kr[i] / p.Wo;
+                const int dl_ow = p.wg_rows == 0 ? b_kr[i] : b_kr[i] % p.Wo;
+                b_ihl[i] = dl_oh * p.stride - p.pad + b_r[i];
+                b_iwl[i] = dl_ow * p.stride - p.pad + b_s[i];
+                b_vo[i] = (unsigned)((int)b_base[i] + (b_ihl[i] * p.W + b_iwl[i]) * p.C + shift) * 4u;
+            }
+        }
+    }
+
     // issues the DMA of the NEXT k-tile into LDS buffer `buf` (state is advanced by BK afterwards)
     auto issue_tiles = [&](float* Ad, float* Bd) {
+        if (FAST) {
+            if (MODE == MODE_FWD || MODE == MODE_DGRAD) {
+                const unsigned sa = (unsigned)u_c0 * 4u;
+                unsigned sb;
+                if (MODE == MODE_FWD) {
+                    sb = u_kb;
+                } else {
+                    const int tapw = (p.r0 + u_r * p.rstep) * p.S + p.s0 + u_s * p.sstep;
+                    sb = (unsigned)((u_c0 * (p.R * p.S) + tapw) * p.C) * 4u;
+                }
+#pragma unroll
+                for (int i = 0; i < A_LD; ++i)
+                    dma16(a_rsrc, lds_addr(Ad) + (unsigned)(i * 256 + wave * 64) * 16u, (p.dbg & 32) ? OOB_OFF : a_vo[i], sa);
+#pragma unroll
+                for (int i = 0; i < B_LD; ++i)
+                    dma16(b_rsrc, lds_addr(Bd) + (unsigned)(i * 256 + wave * 64) * 16u, (p.dbg & 32) ? OOB_OFF : b_vo[i], sb);
+                u_kb += BK * 4;
+                u_c0 += BK;
+                if (u_c0 == ((MODE == MODE_FWD) ? p.C : p.K)) {
+                    u_c0 = 0;
+                    if (++u_s == ((MODE == MODE_FWD) ? p.S : p.ns)) { u_s = 0; ++u_r; }
+                    retap();
+                }
+            } else {
+                const int rows_left = kend - u_kpos;
+                const unsigned sa = (unsigned)(u_kpos * p.K) * 4u;
+                const int ihu = u_oh * p.stride, iwu = u_ow * p.stride;
+                const unsigned sb = (unsigned)(((u_n * p.H + ihu) * p.W + iwu) * p.C) * 4u;
+#pragma unroll
+                for (int i = 0; i < A_LD; ++i) {
+                    const bool ok = a_ok[i] && a_kr[i] < rows_left && !(p.dbg & 32);
+                    dma16(a_rsrc, lds_addr(Ad) + (unsigned)(i * 256 + wave * 64) * 16u, ok ? a_vo[i] : OOB_OFF, sa);
+                }
+#pragma unroll
+                for (int i = 0; i < B_LD; ++i) {
+                    const bool ok = b_ok[i] && b_kr[i] < rows_left && (unsigned)(ihu + b_ihl[i]) < (unsigned)p.H &&
+                                    (unsigned)(iwu + b_iwl[i]) < (unsigned)p.W && !(p.dbg & 32);
+                    dma16(b_rsrc_f, lds_addr(Bd) + (unsigned)(i * 256 + wave * 64) * 16u, ok ? b_vo[i] : OOB_OFF, sb);
+                }
+                u_kpos += BK;
+                if (p.wg_rows == 0) {
+                    u_ow += BK;
+                    if (u_ow >= p.Wo) {
+                        u_ow = 0;
+                        if (++u_oh == p.Ho) { u_oh = 0; ++u_n; }
+                    }
+                } else {
+                    u_oh += p.wg_rows;
+                    if (u_oh >= p.Ho) { u_oh = 0; ++u_n; }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             unsigned off;
@@ -222,7 +356,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                 off = a_base[i] + (unsigned)a_k[i] * (unsigned)p.K;
             }
             if (p.dbg & 32) ok = false;
-            dma16(a_rsrc, lds_addr(Ad) + (unsigned)(i * 256 + wave * 64) * 16u, ok ? off * 4u : OOB_OFF);
+            dma16(a_rsrc, lds_addr(Ad) + (unsigned)(i * 256 + wave * 64) * 16u, ok ? off * 4u : OOB_OFF, 0u);
             a_k[i] += BK;
             if (MODE != MODE_WGRAD) {
                 const int cin = (MODE == MODE_FWD) ? p.C : p.K;
@@ -260,7 +394,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                 }
             }
             if (p.dbg & 32) ok = false;
-            dma16(b_rsrc, lds_addr(Bd) + (unsigned)(i * 256 + wave * 64) * 16u, ok ? off * 4u : OOB_OFF);
+            dma16(b_rsrc, lds_addr(Bd) + (unsigned)(i * 256 + wave * 64) * 16u, ok ? off * 4u : OOB_OFF, 0u);
             b_k[i] += BK;
         }
     };
@@ -467,22 +601,33 @@ int pick_tile(int Mg, int Ng, long splits) {
     return 2;
 }
 
-template <int MODE, int EPI, int BKV, int BF>
+template <int MODE, int EPI, int BKV, int BF, int FAST>
 void launch_tile(IgemmParams& p, int splits, int tile, hipStream_t st) {
     dim3 block(256);
     if (tile == 0) {
         p.tiles_n = cdiv(p.Ng, 128);
         dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, 1, splits);
-        hipLaunchKernelGGL((igemm_kernel<MODE, 128, 128, EPI, BKV, BF>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((igemm_kernel<MODE, 128, 128, EPI, BKV, BF, FAST>), grid, block, 0, st, p);
     } else if (tile == 1) {
         p.tiles_n = cdiv(p.Ng, 64);
         dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, 1, splits);
-        hipLaunchKernelGGL((igemm_kernel<MODE, 128, 64, EPI, BKV, BF>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((igemm_kernel<MODE, 128, 64, EPI, BKV, BF, FAST>), grid, block, 0, st, p);
     } else {
         p.tiles_n = cdiv(p.Ng, 64);
         dim3 grid(cdiv(p.Mg, 64) * p.tiles_n, 1, splits);
-        hipLaunchKernelGGL((igemm_kernel<MODE, 64, 64, EPI, BKV, BF>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((igemm_kernel<MODE, 64, 64, EPI, BKV, BF, FAST>), grid, block, 0, st, p);
     }
+}
+
+// FAST walk eligibility (see igemm_kernel); also fills wg_rows for WGRAD
+template <int MODE>
+bool fast_walk_ok(IgemmParams& p) {
+    if (MODE == MODE_FWD) return p.C % 16 == 0;
+    if (MODE == MODE_DGRAD) return p.K % 16 == 0;
+    // WGRAD: the 16 pixels of a k-tile share one (image, output row) - or cover whole rows of one image
+    if (p.Wo % 16 == 0 || p.N * p.Ho == 1) { p.wg_rows = 0; return true; }
+    if (16 % p.Wo == 0 && p.Ho % (16 / p.Wo) == 0) { p.wg_rows = 16 / p.Wo; return true; }
+    return false;
 }
 
 template <int MODE>
@@ -491,14 +636,16 @@ int launch_igemm(IgemmParams& p, int splits, int tile, hipStream_t st) {
     const bool full = p.bias || p.relu || p.mask_src || p.drop_thr || p.residual || (MODE == MODE_DGRAD && p.hstep != 1);
     if ((size_t)p.Mg * p.Ng * sizeof(float) >= OOB_OFF) return DS6G_ERR_ARG;
     // BK = 32 was measured (tools/bench_igemm.py): within +-5 % on fwd/dgrad, 10-30 % slower on wgrad -> BK = 16
+    const bool fast = fast_walk_ok<MODE>(p) && !(g_dbg & 0x80);
+    const bool epi = MODE != MODE_WGRAD && full;
     if (g_ds6g_bf16) {
-        if (MODE != MODE_WGRAD && full) launch_tile<MODE, 1, 16, 1>(p, splits, tile, st);
-        else launch_tile<MODE, 0, 16, 1>(p, splits, tile, st);
+        if (fast) { if (epi) launch_tile<MODE, 1, 16, 1, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 1, 1>(p, splits, tile, st); }
+        else      { if (epi) launch_tile<MODE, 1, 16, 1, 0>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 1, 0>(p, splits, tile, st); }
     } else {
-        if (MODE != MODE_WGRAD && full) launch_tile<MODE, 1, 16, 0>(p, splits, tile, st);
-        else launch_tile<MODE, 0, 16, 0>(p, splits, tile, st);
+        if (fast) { if (epi) launch_tile<MODE, 1, 16, 0, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 0, 1>(p, splits, tile, st); }
+        else      { if (epi) launch_tile<MODE, 1, 16, 0, 0>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 0, 0>(p, splits, tile, st); }
     }
-    g_last_variant = MODE * 10 + tile;
+    g_last_variant = MODE * 10 + tile + (fast ? 100 : 0);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }
@@ -580,7 +727,7 @@ extern "C" {
 
 int ds6g_last_igemm_variant(void) { return g_last_variant; }
 int ds6g_set_debug_flags(int flags) {
-    g_dbg = flags & 0x3f;
+    g_dbg = flags & 0xbf;  // 0x80: force the general (FAST 0) walk
     g_wgrad_tile = (flags & 0x40) ? 2 : 1;
     if (flags >> 8) g_min_blocks = flags >> 8;
     return 0;

@@ -23,8 +23,9 @@ extern "C" {
 #endif
 
 int ds6g_version(void);
-/* which implicit-GEMM instantiation the last conv/linear call launched: mode*10 + tile
- * (mode 0 fwd, 1 dgrad, 2 wgrad; tile 0 128x128, 1 128x64, 2 64x64).  Bench instrumentation only. */
+/* which implicit-GEMM instantiation the last conv/linear call launched: 100*walk + 10*mode + tile
+ * (walk 1 = wave-uniform k walk, 0 = general walk; mode 0 fwd, 1 dgrad, 2 wgrad; tile 0 128x128, 1 128x64,
+ * 2 64x64).  Bench instrumentation only. */
 int ds6g_last_igemm_variant(void);
 /* ablation switches for kernel timing experiments (results become wrong); 0 = normal operation */
 int ds6g_set_debug_flags(int flags);
