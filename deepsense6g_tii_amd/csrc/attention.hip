@@ -34,10 +34,13 @@ struct AttnParams {
     float* dk;
     float* dv;
     int T, nh, B;
-    int ld;              // row stride (floats) of q/k/v/o/do/dq/dk/dv
+    int ld;              // row stride (floats) of o / do and of the split slabs
+    int ldq;             // row stride of q / k / v (3C when they are column blocks of one fused projection output)
+    int ldd;             // row stride of the final dq / dk / dv
     int splits, tiles_per_split;
     size_t slab;         // floats between split slabs of o / dq / dk / dv
     unsigned bytes;      // size of each [B*T][ld] tensor
+    unsigned bytes_q;    // bytes addressable from the q / k / v pointers
     float scale;
     uint32_t thr;
     float dscale;
@@ -232,6 +235,8 @@ __device__ __forceinline__ void store_rows(const f32x16* acc, float* base, int l
     const int h = by_ % p.nh, split = by_ / p.nh, b = bz_;                                             \
     const int T = p.T;                                                                                 \
     const long head_off = (long)b * T * p.ld + h * HD;                                                 \
+    const long head_offq = (long)b * T * p.ldq + h * HD;                                               \
+    [[maybe_unused]] const long head_offd = (long)b * T * p.ldd + h * HD;                              \
     const int ntiles = (T + 31) / 32;                                                                  \
     const int t_begin = split * p.tiles_per_split;                                                     \
     const int t_end = min(ntiles, t_begin + p.tiles_per_split);                                        \
@@ -244,10 +249,10 @@ template <int HD, int BF>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     ATTN_COMMON();
     const int q_row = bx_ * 128 + wave * 32 + l31;
-    const i32x4 k_srd = make_srd(p.k, p.bytes), v_srd = make_srd(p.v, p.bytes);
+    const i32x4 k_srd = make_srd(p.k, p.bytes_q), v_srd = make_srd(p.v, p.bytes_q);
 
     float qreg[HD / 2];
-    load_frag<HD>(qreg, p.q, head_off + (long)(q_row < T ? q_row : T - 1) * p.ld, half, p.scale);
+    load_frag<HD>(qreg, p.q, head_offq + (long)(q_row < T ? q_row : T - 1) * p.ldq, half, p.scale);
     f32x16 oacc[NB];
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk)
@@ -258,8 +263,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 
     auto step = [&](const float* Kcp, const float* Vcp, const float* Kn, const float* Vn, int kt, bool more) {
         if (more) {
-            tile_dma<HD>(k_srd, Kn, (unsigned)head_off, (kt + 1) * 32, T, p.ld, wave, lane);
-            tile_dma<HD>(v_srd, Vn, (unsigned)head_off, (kt + 1) * 32, T, p.ld, wave, lane);
+            tile_dma<HD>(k_srd, Kn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
+            tile_dma<HD>(v_srd, Vn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
         }
         const unsigned Kc = opaque_tile(Kcp), Vc = opaque_tile(Vcp);
         f32x16 s;
@@ -302,8 +307,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     };
 
     if (t_begin < t_end) {
-        tile_dma<HD>(k_srd, Xa0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
-        tile_dma<HD>(v_srd, Xb0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
+        tile_dma<HD>(k_srd, Xa0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
+        tile_dma<HD>(v_srd, Xb0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -360,13 +365,13 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
     ATTN_COMMON();
     const int q_row = bx_ * 128 + wave * 32 + l31;
     const bool q_ok = q_row < T;
-    const i32x4 k_srd = make_srd(p.k, p.bytes), v_srd = make_srd(p.v, p.bytes);
+    const i32x4 k_srd = make_srd(p.k, p.bytes_q), v_srd = make_srd(p.v, p.bytes_q);
 
     float qreg[HD / 2], doreg[HD / 2];
     float delta = 0.f;
     {
         const long ro = head_off + (long)(q_ok ? q_row : T - 1) * p.ld;
-        load_frag<HD>(qreg, p.q, ro, half, p.scale);
+        load_frag<HD>(qreg, p.q, head_offq + (long)(q_ok ? q_row : T - 1) * p.ldq, half, p.scale);
         load_frag<HD>(doreg, p.d_o, ro, half, q_ok ? 1.f : 0.f);
 #pragma unroll
         for (int j = 0; j < HD / 8; ++j) {
@@ -389,8 +394,8 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
 
     auto step = [&](const float* Kcp, const float* Vcp, const float* Kn, const float* Vn, int kt, bool more) {
         if (more) {
-            tile_dma<HD>(k_srd, Kn, (unsigned)head_off, (kt + 1) * 32, T, p.ld, wave, lane);
-            tile_dma<HD>(v_srd, Vn, (unsigned)head_off, (kt + 1) * 32, T, p.ld, wave, lane);
+            tile_dma<HD>(k_srd, Kn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
+            tile_dma<HD>(v_srd, Vn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
         }
         const unsigned Kc = opaque_tile(Kcp), Vc = opaque_tile(Vcp);
         f32x16 s, dp;
@@ -414,8 +419,8 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
     };
 
     if (t_begin < t_end) {
-        tile_dma<HD>(k_srd, Xa0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
-        tile_dma<HD>(v_srd, Xb0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
+        tile_dma<HD>(k_srd, Xa0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
+        tile_dma<HD>(v_srd, Xb0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -423,7 +428,8 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
         step(Xa0, Xb0, Xa1, Xb1, kt, kt + 1 < t_end);
         if (kt + 1 < t_end) step(Xa1, Xb1, Xa0, Xb0, kt + 1, kt + 2 < t_end);
     }
-    store_rows<HD>(dq, p.dq + (size_t)split * p.slab + head_off, p.ld, q_row, T, half, 1.0f);
+    if (p.splits == 1) store_rows<HD>(dq, p.dq + head_offd, p.ldd, q_row, T, half, 1.0f);
+    else store_rows<HD>(dq, p.dq + (size_t)split * p.slab + head_off, p.ld, q_row, T, half, 1.0f);
 }
 
 // dK, dV: one wave = 32 keys (key on the lane), loop over (a split of) the query tiles.
@@ -437,11 +443,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
     __shared__ float delta_s[2][32];
     const int key = bx_ * 128 + wave * 32 + l31;
     const bool key_ok = key < T;
-    const i32x4 q_srd = make_srd(p.q, p.bytes), do_srd = make_srd(p.d_o, p.bytes);
+    const i32x4 q_srd = make_srd(p.q, p.bytes_q), do_srd = make_srd(p.d_o, p.bytes);
 
     float kreg[HD / 2], vreg[HD / 2];
     {
-        const long ro = head_off + (long)(key_ok ? key : T - 1) * p.ld;
+        const long ro = head_offq + (long)(key_ok ? key : T - 1) * p.ldq;
         load_frag<HD>(kreg, p.k, ro, half, 1.f);
         if (DO_DK) load_frag<HD>(vreg, p.v, ro, half, 1.f);
     }
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
     };
     auto step = [&](const float* Qcp, const float* Ocp, const float* Qn, const float* On, int qt, int buf, bool more) {
         if (more) {
-            tile_dma<HD>(q_srd, Qn, (unsigned)head_off, (qt + 1) * 32, T, p.ld, wave, lane);
+            tile_dma<HD>(q_srd, Qn, (unsigned)head_offq, (qt + 1) * 32, T, p.ldq, wave, lane);
             tile_dma<HD>(do_srd, On, (unsigned)head_off, (qt + 1) * 32, T, p.ld, wave, lane);
             stats(qt + 1, buf ^ 1);
         }
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
     };
 
     if (t_begin < t_end) {
-        tile_dma<HD>(q_srd, Xa0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
+        tile_dma<HD>(q_srd, Xa0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
         tile_dma<HD>(do_srd, Xb0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
         stats(t_begin, 0);
     }
@@ -510,18 +516,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
         step(Xa0, Xb0, Xa1, Xb1, qt, 0, qt + 1 < t_end);
         if (qt + 1 < t_end) step(Xa1, Xb1, Xa0, Xb0, qt + 1, 1, qt + 2 < t_end);
     }
-    if (DO_DK) store_rows<HD>(dk, p.dk + (size_t)split * p.slab + head_off, p.ld, key, T, half, 1.0f);
-    if (DO_DV) store_rows<HD>(dv, p.dv + (size_t)split * p.slab + head_off, p.ld, key, T, half, 1.0f);
+    if (p.splits == 1) {
+        if (DO_DK) store_rows<HD>(dk, p.dk + head_offd, p.ldd, key, T, half, 1.0f);
+        if (DO_DV) store_rows<HD>(dv, p.dv + head_offd, p.ldd, key, T, half, 1.0f);
+    } else {
+        if (DO_DK) store_rows<HD>(dk, p.dk + (size_t)split * p.slab + head_off, p.ld, key, T, half, 1.0f);
+        if (DO_DV) store_rows<HD>(dv, p.dv + (size_t)split * p.slab + head_off, p.ld, key, T, half, 1.0f);
+    }
 }
 
-// out = sum_s part[s]   (dq / dk / dv split slabs)
-__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ part, float* __restrict__ out, long n4,
-                                                       int splits, size_t slab) {
+// out[row][0..cols) = sum_s part[s][row][0..cols)   (dq / dk / dv split slabs; rows of stride ld_in -> ld_out).
+// blockIdx.y picks the (part, out) pair, so dK and dV are reduced by one launch.
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ part0, float* __restrict__ out0,
+                                                       const float* __restrict__ part1, float* __restrict__ out1,
+                                                       long n4, int cols4, int ld_in, int ld_out, int splits, size_t slab) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
-    f32x4 s = *reinterpret_cast<const f32x4*>(part + i * 4);
-    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(part + (size_t)k * slab + i * 4);
-    *reinterpret_cast<f32x4*>(out + i * 4) = s;
+    const float* part = blockIdx.y ? part1 : part0;
+    float* out = blockIdx.y ? out1 : out0;
+    const long row = i / cols4;
+    const int c = (int)(i - row * cols4) * 4;
+    const float* src = part + row * ld_in + c;
+    f32x4 s = *reinterpret_cast<const f32x4*>(src);
+    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(src + (size_t)k * slab);
+    *reinterpret_cast<f32x4*>(out + row * ld_out + c) = s;
 }
 
 // number of loop splits: fills the chip evenly.  cap = workgroups resident at once (256 CUs x per-CU residency)
@@ -585,17 +603,19 @@ size_t ds6g_attention_workspace_bytes(int B, int T, int nh, int hd, int ld) {
 
 // o = dropout(softmax(q k^T / sqrt(hd))) v ; lse[b][h][t] = logsumexp of the scaled scores
 int ds6g_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int T, int nh,
-                       int hd, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws, size_t ws_bytes,
-                       void* stream) {
+                       int hd, int ld_qkv, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
+                       size_t ws_bytes, void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(q && k && v && o && lse && B > 0 && T > 0 && ld % 4 == 0 && ld >= nh * hd);
+    DS6G_CHECK_ARG(ld_qkv % 4 == 0 && ld_qkv >= nh * hd && (size_t)B * T * ld_qkv * sizeof(float) < OOB_OFF);
     DS6G_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
     const size_t slab = (size_t)B * T * ld;
     DS6G_CHECK_ARG(slab * sizeof(float) < OOB_OFF);
     hipStream_t st = (hipStream_t)stream;
     AttnParams p{};
-    p.q = q; p.k = k; p.v = v; p.lse = lse; p.T = T; p.nh = nh; p.B = B; p.ld = ld;
+    p.q = q; p.k = k; p.v = v; p.lse = lse; p.T = T; p.nh = nh; p.B = B; p.ld = ld; p.ldq = ld_qkv; p.ldd = ld;
     p.bytes = (unsigned)(slab * sizeof(float)); p.slab = slab;
+    p.bytes_q = (unsigned)((((size_t)B * T - 1) * ld_qkv + nh * hd) * sizeof(float));
     p.scale = 1.0f / sqrtf((float)hd);
     p.thr = ds6g_drop_threshold(drop_p); p.dscale = 1.f / (1.f - drop_p); p.seed = seed; p.seed_off = seed_off;
     const int ntiles = cdiv(T, 32);
@@ -622,21 +642,26 @@ int ds6g_attention_fwd(const float* q, const float* k, const float* v, float* o,
 // gradients of the above; delta is a [B][nh][T] scratch (rowsum(dO*O)), written then read
 int ds6g_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                        const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int T, int nh, int hd,
-                       int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws, size_t ws_bytes, void* stream) {
+                       int ld_qkv, int ld, int ld_dqkv, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
+                       size_t ws_bytes, void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(q && k && v && o && d_o && lse && delta && dq && dk && dv && ld % 4 == 0 && ld >= nh * hd);
+    DS6G_CHECK_ARG(ld_qkv % 4 == 0 && ld_qkv >= nh * hd && (size_t)B * T * ld_qkv * sizeof(float) < OOB_OFF);
+    DS6G_CHECK_ARG(ld_dqkv % 4 == 0 && ld_dqkv >= nh * hd);
     const size_t slab = (size_t)B * T * ld;
     DS6G_CHECK_ARG(slab * sizeof(float) < OOB_OFF);
     hipStream_t st = (hipStream_t)stream;
     AttnParams p{};
     p.q = q; p.k = k; p.v = v; p.o = const_cast<float*>(o); p.lse = const_cast<float*>(lse); p.d_o = d_o;
-    p.delta = delta; p.T = T; p.nh = nh; p.B = B; p.ld = ld;
+    p.delta = delta; p.T = T; p.nh = nh; p.B = B; p.ld = ld; p.ldq = ld_qkv; p.ldd = ld_dqkv;
     p.bytes = (unsigned)(slab * sizeof(float)); p.slab = slab;
+    p.bytes_q = (unsigned)((((size_t)B * T - 1) * ld_qkv + nh * hd) * sizeof(float));
     p.scale = 1.0f / sqrtf((float)hd);
     p.thr = ds6g_drop_threshold(drop_p); p.dscale = 1.f / (1.f - drop_p); p.seed = seed; p.seed_off = seed_off;
     const int ntiles = cdiv(T, 32);
     const int blocks128 = cdiv(T, 128);
-    const long n4 = (long)slab / 4;
+    const int cols4 = nh * hd / 4;
+    const long n4 = (long)B * T * cols4;
     // ---- dQ (split over keys)
     {
         const size_t max_by_ws = ws ? ws_bytes / (slab * sizeof(float)) : 1;
@@ -649,7 +674,8 @@ int ds6g_attention_bwd(const float* q, const float* k, const float* v, const flo
         int rc = launch_hd<1>(p, hd, dim3(blocks128, nh * splits, B), st);
         if (rc) return rc;
         if (splits > 1) {
-            hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, (const float*)ws, dq, n4, splits, slab);
+            hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256), 1), dim3(256), 0, st, (const float*)ws, dq,
+                               (const float*)nullptr, (float*)nullptr, n4, cols4, ld, ld_dqkv, splits, slab);
             DS6G_LAUNCH_CHECK();
         }
     }
@@ -666,9 +692,8 @@ int ds6g_attention_bwd(const float* q, const float* k, const float* v, const flo
         int rc = launch_hd<2>(p, hd, dim3(blocks128, nh * splits, B), st);
         if (rc) return rc;
         if (splits > 1) {
-            hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, (const float*)wsf, dk, n4, splits, slab);
-            hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st,
-                               (const float*)(wsf + (size_t)splits * slab), dv, n4, splits, slab);
+            hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256), 2), dim3(256), 0, st, (const float*)wsf, dk,
+                               (const float*)(wsf + (size_t)splits * slab), dv, n4, cols4, ld, ld_dqkv, splits, slab);
             DS6G_LAUNCH_CHECK();
         }
     }

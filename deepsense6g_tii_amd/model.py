@@ -208,6 +208,7 @@ class TransFuser(nn.Module):
         self._ws_side = {}
         self._side_streams = None
         self.multi_stream = True  # run the three (independent) trunks on three HIP streams between fusion points
+        self.fuse_qkv = True      # key|query|value projections as one GEMM when their parameters are contiguous (arena)
         self._anchor = None
         self._arena = None
         if self.device.type == "cuda":
@@ -234,9 +235,47 @@ class TransFuser(nn.Module):
                 return 2 + 2 * (4 - s)
         return 9
 
+    @staticmethod
+    def _group_qkv(named):
+        """Lay the key / query / value projections of every SelfAttention (model2_seq.py:83-85) out as ONE
+        [3C, C] weight block followed by ONE [3C] bias block, so the three projections run as a single GEMM
+        (and their gradients as a single wgrad / dgrad) straight on the arena."""
+        order = {"key.weight": 0, "query.weight": 1, "value.weight": 2, "key.bias": 3, "query.bias": 4, "value.bias": 5}
+        out, i = [], 0
+        while i < len(named):
+            name = named[i][0]
+            if name.endswith(".attn.key.weight"):
+                grp = named[i:i + 6]
+                pref = name[: -len("key.weight")]
+                assert all(n.startswith(pref) and n[len(pref):] in order for n, _ in grp), [n for n, _ in grp]
+                out.extend(sorted(grp, key=lambda kv: order[kv[0][len(pref):]]))
+                i += 6
+            else:
+                out.append(named[i])
+                i += 1
+        return out
+
+    def _qkv_fused(self, at, grads=False):
+        """(weight ptr, bias ptr) of the fused key|query|value block when the three projections are contiguous in
+        memory right now (arena or EMA-shadow layout; param.data may have been re-pointed), else None."""
+        C = at.key.weight.shape[0]
+        if grads:
+            w = [self._g(m.weight) for m in (at.key, at.query, at.value)]
+            b = [self._g(m.bias) for m in (at.key, at.query, at.value)]
+            if len({f for _, f in w + b}) != 1:
+                return None
+            wp, bp = [x for x, _ in w], [x for x, _ in b]
+        else:
+            wp = [self._w(m.weight) for m in (at.key, at.query, at.value)]
+            bp = [self._w(m.bias) for m in (at.key, at.query, at.value)]
+        if wp[1] == wp[0] + 4 * C * C and wp[2] == wp[0] + 8 * C * C and bp[1] == bp[0] + 4 * C and bp[2] == bp[0] + 8 * C:
+            return wp[0], bp[0]
+        return None
+
     def _build_arena(self):
         dev = self.device
         named = sorted(self.named_parameters(), key=lambda kv: self._milestone(kv[0]))  # stable
+        named = self._group_qkv(named)
         total = sum((p.numel() + 3) // 4 * 4 for _, p in named)
         self._arena = torch.zeros(total, dtype=F32, device=dev)
         self._garena = torch.zeros(total, dtype=F32, device=dev)
@@ -473,9 +512,14 @@ class TransFuser(nn.Module):
         pr = cfg.resid_pdrop if train else 0.0
         at = blk.attn
         h, m1, r1 = ops.layernorm_fwd(x, self._w(blk.ln1.weight), self._w(blk.ln1.bias), blk.ln1.eps)
-        q = ops.linear_fwd(h, self._w(at.query.weight), self._w(at.query.bias), C)
-        k = ops.linear_fwd(h, self._w(at.key.weight), self._w(at.key.bias), C)
-        v = ops.linear_fwd(h, self._w(at.value.weight), self._w(at.value.bias), C)
+        fused = self._qkv_fused(at) if self.fuse_qkv else None
+        if fused is not None:  # one GEMM, columns key | query | value
+            kqv = ops.linear_fwd(h, fused[0], fused[1], 3 * C)
+            k, q, v = kqv[:, :C], kqv[:, C:2 * C], kqv[:, 2 * C:]
+        else:
+            q = ops.linear_fwd(h, self._w(at.query.weight), self._w(at.query.bias), C)
+            k = ops.linear_fwd(h, self._w(at.key.weight), self._w(at.key.bias), C)
+            v = ops.linear_fwd(h, self._w(at.value.weight), self._w(at.value.bias), C)
         off_a = self._next_drop(B * nh * T * T) if pa > 0 else 0
         y, lse = ops.attention_fwd(q, k, v, B, T, nh, self._ws, pa, self._seed, off_a)
         off_p = self._next_drop(x.numel()) if pr > 0 else 0
@@ -665,13 +709,22 @@ class TransFuser(nn.Module):
         dz1 = ops.dropout(dx1, pr, self._seed, off_p) if pr > 0 else dx1
         self._lin_param_grads(at.proj, y, dz1)
         dy = ops.linear_dgrad(dz1, self._w(at.proj.weight), C)
-        dq, dk, dv = ops.attention_bwd(q, k, v, y, dy, lse, B, T, nh, self._ws, pa, self._seed, off_a)
-        self._lin_param_grads(at.query, h, dq)
-        self._lin_param_grads(at.key, h, dk)
-        self._lin_param_grads(at.value, h, dv)
-        dh = ops.linear_dgrad(dq, self._w(at.query.weight), C)
-        ops.linear_dgrad(dk, self._w(at.key.weight), C, out=dh, accumulate=True)
-        ops.linear_dgrad(dv, self._w(at.value.weight), C, out=dh, accumulate=True)
+        fw = self._qkv_fused(at) if self.fuse_qkv else None
+        fg = self._qkv_fused(at, grads=True) if fw is not None else None
+        if fg is not None:  # gradients of the fused projection: one [M, 3C] matrix, one wgrad, one dgrad
+            dkqv = torch.empty((dy.shape[0], 3 * C), dtype=F32, device=dy.device)
+            ops.attention_bwd(q, k, v, y, dy, lse, B, T, nh, self._ws, pa, self._seed, off_a,
+                              out=(dkqv[:, C:2 * C], dkqv[:, :C], dkqv[:, 2 * C:]))
+            ops.linear_wgrad(h, dkqv, fg[0], self._ws, accumulate=bool(self._g(at.key.weight)[1]), dbias_ptr=fg[1])
+            dh = ops.linear_dgrad(dkqv, fw[0], C)
+        else:
+            dq, dk, dv = ops.attention_bwd(q, k, v, y, dy, lse, B, T, nh, self._ws, pa, self._seed, off_a)
+            self._lin_param_grads(at.query, h, dq)
+            self._lin_param_grads(at.key, h, dk)
+            self._lin_param_grads(at.value, h, dv)
+            dh = ops.linear_dgrad(dq, self._w(at.query.weight), C)
+            ops.linear_dgrad(dk, self._w(at.key.weight), C, out=dh, accumulate=True)
+            ops.linear_dgrad(dv, self._w(at.value.weight), C, out=dh, accumulate=True)
         g1w, a1 = self._g(blk.ln1.weight)
         g1b, _ = self._g(blk.ln1.bias)
         dx = ops.layernorm_bwd(dh, x, m1, r1, self._w(blk.ln1.weight), g1w, g1b, self._ws, add=dx1,

@@ -173,27 +173,42 @@ def layernorm_bwd(dy, x, mean, rstd, gamma_ptr, dgamma_ptr, dbeta_ptr, ws: Works
 
 
 # ------------------------------------------------------------------------------------------------
+def _rows(t, M, C):
+    """2-D fp32 operand whose rows may be a column block of a wider matrix -> row stride in floats"""
+    assert t.dtype == F32 and t.is_cuda and tuple(t.shape) == (M, C) and t.stride(1) == 1 and t.stride(0) % 4 == 0, \
+        (t.dtype, tuple(t.shape), t.stride())
+    return t.stride(0)
+
+
 def attention_fwd(q, k, v, B, T, nh, ws: Workspace, drop_p=0.0, seed=0, seed_off=0):
+    """q, k, v: [B*T, C] each, contiguous or column blocks of one fused projection output (same row stride)."""
     M, C = q.shape
     assert M == B * T
-    for t in (q, k, v):
-        _chk(t, M, C)
-    o = torch.empty_like(q)
+    ldq = _rows(q, M, C)
+    assert _rows(k, M, C) == ldq and _rows(v, M, C) == ldq
+    o = torch.empty((M, C), dtype=F32, device=q.device)
     lse = torch.empty((B, nh, T), dtype=F32, device=q.device)
-    lib().attention_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, T, nh, C // nh, C, float(drop_p), seed, seed_off,
+    lib().attention_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, T, nh, C // nh, ldq, C, float(drop_p), seed, seed_off,
                         ws.ptr, ws.nbytes, _stream())
     return o, lse
 
 
-def attention_bwd(q, k, v, o, d_o, lse, B, T, nh, ws: Workspace, drop_p=0.0, seed=0, seed_off=0):
+def attention_bwd(q, k, v, o, d_o, lse, B, T, nh, ws: Workspace, drop_p=0.0, seed=0, seed_off=0, out=None):
+    """-> (dq, dk, dv); `out` = three [B*T, C] views with one common row stride (column blocks of a fused matrix)."""
     M, C = q.shape
-    for t in (q, k, v, o, d_o):
+    ldq = _rows(q, M, C)
+    assert _rows(k, M, C) == ldq and _rows(v, M, C) == ldq
+    for t in (o, d_o):
         _chk(t, M, C)
     _chk(lse, B, nh, T)
     delta = torch.empty_like(lse)
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    if out is None:
+        out = tuple(torch.empty((M, C), dtype=F32, device=q.device) for _ in range(3))
+    dq, dk, dv = out
+    ldd = _rows(dq, M, C)
+    assert _rows(dk, M, C) == ldd and _rows(dv, M, C) == ldd
     lib().attention_bwd(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, T, nh,
-                        C // nh, C, float(drop_p), seed, seed_off, ws.ptr, ws.nbytes, _stream())
+                        C // nh, ldq, C, ldd, float(drop_p), seed, seed_off, ws.ptr, ws.nbytes, _stream())
     return dq, dk, dv
 
 

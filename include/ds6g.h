@@ -78,15 +78,18 @@ size_t ds6g_colsum_workspace_bytes(long M, int C);
 int ds6g_colsum(const float* x, long M, int C, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- attention.hip : SelfAttention core, model2_seq.py:101-106 (softmax(q k^T/sqrt(hd)), attn_drop,
- * att @ v, head merge).  q/k/v/o: [B*T][ld], head h at columns h*hd.  hd in {16,32,64,128}.
+ * att @ v, head merge).  Head h lives at columns h*hd of every operand.  q/k/v: [B*T][ld_qkv] (ld_qkv = 3C when
+ * they are column blocks of ONE fused key|query|value projection output, model2_seq.py:97-99); o / d_o: [B*T][ld];
+ * dq/dk/dv: [B*T][ld_dqkv] (again 3C to write one fused gradient matrix).  hd in {16,32,64,128}.
  * ws: scratch for the split-loop partial results (any size; more allows more splits, see *_workspace_bytes). */
 size_t ds6g_attention_workspace_bytes(int B, int T, int nh, int hd, int ld);
 int ds6g_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int T, int nh,
-                       int hd, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws, size_t ws_bytes,
-                       void* stream);
+                       int hd, int ld_qkv, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
+                       size_t ws_bytes, void* stream);
 int ds6g_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                        const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int T, int nh, int hd,
-                       int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws, size_t ws_bytes, void* stream);
+                       int ld_qkv, int ld, int ld_dqkv, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
+                       size_t ws_bytes, void* stream);
 
 /* ---- spatial.hip -------------------------------------------------------------------------------*/
 /* normalize_imagenet + stack + NCHW->NHWC: model2_seq.py:36-45,481-482,491-493 */

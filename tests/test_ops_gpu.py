@@ -256,6 +256,27 @@ def test_attention(dev, B, T, nh, hd):
     close(dv, v.grad, 1e-4, 2e-5)
 
 
+@pytest.mark.parametrize("hd,T", [(16, 962), (128, 77)])
+def test_attention_fused_qkv_layout(dev, hd, T):
+    """q/k/v and dq/dk/dv as column blocks of one [M, 3C] matrix (the fused key|query|value projection of the model)
+    must give bit-identical results to separate contiguous operands."""
+    ops = _ops()
+    B, nh = 2, 4
+    C = nh * hd
+    g = torch.Generator().manual_seed(7)
+    kqv = torch.randn(B * T, 3 * C, generator=g).cuda()
+    k, q, v = kqv[:, :C], kqv[:, C:2 * C], kqv[:, 2 * C:]
+    do = torch.randn(B * T, C, generator=g).cuda()
+    ws = ops.Workspace(dev, 512 << 20)
+    o_ref, lse_ref = ops.attention_fwd(q.contiguous(), k.contiguous(), v.contiguous(), B, T, nh, ws)
+    ref = ops.attention_bwd(q.contiguous(), k.contiguous(), v.contiguous(), o_ref, do, lse_ref, B, T, nh, ws)
+    o, lse = ops.attention_fwd(q, k, v, B, T, nh, ws)
+    assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref)
+    dkqv = torch.full((B * T, 3 * C), float("nan"), device=dev)
+    ops.attention_bwd(q, k, v, o, do, lse, B, T, nh, ws, out=(dkqv[:, C:2 * C], dkqv[:, :C], dkqv[:, 2 * C:]))
+    assert torch.equal(dkqv[:, C:2 * C], ref[0]) and torch.equal(dkqv[:, :C], ref[1]) and torch.equal(dkqv[:, 2 * C:], ref[2])
+
+
 def test_attention_dropout(dev):
     """With dropout the forward must equal (P * mask / (1-p)) V for SOME Bernoulli(1-p) mask, and the
     backward must use the same mask.  The mask is recovered from the kernel itself with V = identity."""

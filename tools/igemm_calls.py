@@ -10,6 +10,7 @@ from deepsense6g_tii_amd.train import FusedAdamW, train_iteration
 
 dev = torch.device("cuda:0")
 ops.set_compute_mode(os.environ.get("DTYPE", "f32"))
+lib().set_debug_flags(int(os.environ.get("DBG", "0")))
 model = TransFuser(GlobalConfig(), dev); model.train(); model.multi_stream = False
 opt = FusedAdamW(model, lr=1e-4)
 batch = make_batch(int(os.environ.get("B", "12")), seed=100, device=dev)[:5]
