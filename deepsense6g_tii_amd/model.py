@@ -409,15 +409,27 @@ class TransFuser(nn.Module):
         return off
 
     # ---------------------------------------------------------------- public --------------------
-    def forward(self, image_list, lidar_list, radar_list, gps, rebuild_modality_feat_list=None):
-        if self.device.type != "cuda":
-            raise RuntimeError("deepsense6g_tii_amd.TransFuser runs on MI355X HIP kernels only (no CPU path)")
+    def _inputs(self, image_list, lidar_list, radar_list, gps):
+        """reference-style lists of NCHW frames (cast to fp32 on the device as Engine.train does, train2_seq.py:
+        111-116) - or one data.PackedInputs whose tensors are already in the stem's NHWC x4 layout."""
+        from .data import PackedInputs
         cfg = self.config
+        if isinstance(image_list, PackedInputs):
+            pk = image_list
+            assert lidar_list is None and radar_list is None and gps is None, "PackedInputs carries every modality"
+            assert pk.seq_len == cfg.seq_len, (pk.seq_len, cfg.seq_len)
+            cfg.n_views = 1
+            return pk.images, pk.lidars, pk.radars, pk.gps.to(self.device, F32).contiguous()
         cfg.n_views = len(image_list) // cfg.seq_len  # side effect kept from model2_seq.py:489
         images = [t.to(self.device, F32).contiguous() for t in image_list]
         lidars = [t.to(self.device, F32).contiguous() for t in lidar_list]
         radars = [t.to(self.device, F32).contiguous() for t in radar_list]
-        gps = gps.to(self.device, F32).contiguous()
+        return images, lidars, radars, gps.to(self.device, F32).contiguous()
+
+    def forward(self, image_list, lidar_list=None, radar_list=None, gps=None, rebuild_modality_feat_list=None):
+        if self.device.type != "cuda":
+            raise RuntimeError("deepsense6g_tii_amd.TransFuser runs on MI355X HIP kernels only (no CPU path)")
+        images, lidars, radars, gps = self._inputs(image_list, lidar_list, radar_list, gps)
         if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
             return _FusionFn.apply(self._anchor, self, images, lidars, radars, gps)
         logits, _ = self._run_forward(images, lidars, radars, gps, record=False)
@@ -426,12 +438,7 @@ class TransFuser(nn.Module):
     def train_step_loss(self, image_list, lidar_list, radar_list, gps, target, alpha=0.25, gamma=2.0):
         """Fused forward -> sigmoid focal loss -> backward without autograd (the harness path).
         Returns (loss tensor [1], logits)."""
-        cfg = self.config
-        cfg.n_views = len(image_list) // cfg.seq_len
-        images = [t.to(self.device, F32).contiguous() for t in image_list]
-        lidars = [t.to(self.device, F32).contiguous() for t in lidar_list]
-        radars = [t.to(self.device, F32).contiguous() for t in radar_list]
-        gps = gps.to(self.device, F32).contiguous()
+        images, lidars, radars, gps = self._inputs(image_list, lidar_list, radar_list, gps)
         target = target.to(self.device, F32).contiguous()
         logits, tape = self._run_forward(images, lidars, radars, gps, record=True)
         loss = torch.empty(1, dtype=F32, device=self.device)
@@ -464,13 +471,17 @@ class TransFuser(nn.Module):
     def _stem_fwd(self, trunk, cin, normalize, frames, train):
         L = lib()
         st = ops._stream()
-        B = frames[0].shape[0]
-        S = len(frames)
-        H, W = frames[0].shape[2:]
-        x = torch.empty((B * S, H, W, 4), dtype=F32, device=self.device)
-        for t, f in enumerate(frames):
-            assert f.shape == (B, cin, H, W), (f.shape, (B, cin, H, W))
-            L.pack_input(f.data_ptr(), x.data_ptr(), B, cin, H, W, 4, S, t, int(normalize), st)
+        if torch.is_tensor(frames):  # data.PackedInputs: already NHWC x4, normalised
+            x = frames
+            assert x.dim() == 4 and x.shape[3] == 4 and x.dtype == F32 and x.is_contiguous() and x.device == self.device
+        else:
+            B = frames[0].shape[0]
+            S = len(frames)
+            H, W = frames[0].shape[2:]
+            x = torch.empty((B * S, H, W, 4), dtype=F32, device=self.device)
+            for t, f in enumerate(frames):
+                assert f.shape == (B, cin, H, W), (f.shape, (B, cin, H, W))
+                L.pack_input(f.data_ptr(), x.data_ptr(), B, cin, H, W, 4, S, t, int(normalize), st)
         wpad = torch.empty((64, 7, 7, 4), dtype=F32, device=self.device)
         L.pad_channels(self._w(trunk.conv1.weight), wpad.data_ptr(), 64 * 49, cin, 4, 0, 0, st)
         c1 = ops.conv2d_fwd(x, wpad.data_ptr(), 64, 7, 7, 2, 3)
@@ -582,8 +593,12 @@ class TransFuser(nn.Module):
         cfg = self.config
         train = self.training
         S = cfg.seq_len
-        B = lidars[0].shape[0]
-        assert len(lidars) == S and len(radars) == S and len(images) == cfg.n_views * S
+        if torch.is_tensor(lidars):
+            B = lidars.shape[0] // S
+            assert images.shape[0] == B * S and radars.shape[0] == B * S
+        else:
+            B = lidars[0].shape[0]
+            assert len(lidars) == S and len(radars) == S and len(images) == cfg.n_views * S
         assert gps.shape == (B, 2, 2), gps.shape
         if train:
             self._nbt.add_(1)

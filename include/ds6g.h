@@ -91,6 +91,29 @@ int ds6g_attention_bwd(const float* q, const float* k, const float* v, const flo
                        int ld_qkv, int ld, int ld_dqkv, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
                        size_t ws_bytes, void* stream);
 
+/* ---- input.hip : device-side counterpart of CARLA_Data.__getitem__, data2_seq.py:42-173 --------
+ * pack_image_u8: decoded RGB frame batch [B][H][W][3] uint8 (data2_seq.py:110-141, before its HWC->CHW transpose) ->
+ *   frame slot t of the NHWC x4 stem input [(b*frames_per_sample + t)][H][W][4], cast + normalize_imagenet
+ *   (model2_seq.py:36-45) fused; flip mirrors W (data2_seq.py:144-146).
+ * lidar_bev_count / lidar_bev_finish: lidar_to_histogram_features (data2_seq.py:177-211).  points: float64
+ *   [npoints][point_stride] (x, y first) of nclouds clouds back to back, cloud c = [cloud_offsets[c],
+ *   cloud_offsets[c+1]); xedges / yedges: nbins+1 float64 bin edges - one set, or one per cloud when edges_per_cloud
+ *   (the per-scenario custom field of view, data2_seq.py:190-202) - (np.linspace in the reference, np.histogramdd
+ *   semantics: half-open bins, last bin closed, outliers dropped); counts: [nclouds][nbins][nbins] uint32, must be zero
+ *   on entry.  finish writes min(count, cap)/cap into channel 0 of frame slot t of an NHWC xCd tensor (flip mirrors
+ *   the y axis, data2_seq.py:157-158) and re-zeroes counts.
+ * soft_beam_target: target[b][k] = 1.25 * N(k; beamidx[b], 0.5) for |k - beamidx[b]| <= 5 else 0 (data2_seq.py:160-170);
+ *   flip mirrors the beam axis and writes beamidx_out[b] = nbeams-1-beamidx[b] (nullable). */
+int ds6g_pack_image_u8(const uint8_t* src_hwc, float* dst, int B, int H, int W, int frames_per_sample, int t, int flip,
+                       void* stream);
+int ds6g_lidar_bev_count(const double* points, int point_stride, const long* cloud_offsets, int nclouds,
+                         long npoints, const double* xedges, const double* yedges, int edges_per_cloud, int nbins,
+                         unsigned* counts, void* stream);
+int ds6g_lidar_bev_finish(unsigned* counts, float* dst, int B, int nbins, int Cd, int frames_per_sample, int t, int flip,
+                          int cap, void* stream);
+int ds6g_soft_beam_target(const int* beamidx, float* target, int* beamidx_out, int B, int nbeams, int flip,
+                          void* stream);
+
 /* ---- spatial.hip -------------------------------------------------------------------------------*/
 /* normalize_imagenet + stack + NCHW->NHWC: model2_seq.py:36-45,481-482,491-493 */
 int ds6g_pack_input(const float* src, float* dst, int B, int Cs, int H, int W, int Cd, int frames_per_sample, int t,

@@ -1,0 +1,105 @@
+"""GPU: csrc/input.hip (device-side counterpart of CARLA_Data.__getitem__) against oracle/data_ref.py.
+Integer / byte work is checked bit-exact; the float outputs are bit-exact too because the kernels run the reference's
+own operation sequence."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(B, S, seed, fov):
+    from oracle import data_ref as dr
+    rng = np.random.default_rng(seed)
+    addresses = [f"scenario3{1 + (b % 4)}/x.ply" for b in range(B)]
+    images = [rng.integers(0, 256, (B, 256, 256, 3), dtype=np.uint8) for _ in range(S)]
+    clouds = [[dr.make_cloud(int(rng.integers(0, 30000)) if (b + t) % 5 else 0 if b == 1 else 40, seed * 100 + t * 10 + b,
+                             *dr.fov_edges(addresses[b], fov)) for b in range(B)] for t in range(S)]
+    radars = [rng.random((B, 2, 256, 256), dtype=np.float32) for _ in range(S)]
+    gps = rng.uniform(-1.5, 1.5, (B, 2, 2))
+    beam = rng.integers(0, 64, B)
+    return addresses, images, clouds, radars, gps, beam
+
+
+@pytest.mark.parametrize("flip,fov", [(False, False), (True, True)])
+def test_pipeline_bit_exact_vs_oracle(dev, flip, fov):
+    from deepsense6g_tii_amd.data import DeviceInputPipeline
+    from oracle import data_ref as dr
+    B, S = 3, 2
+    addresses, images, clouds, radars, gps, beam = _mk(B, S, 7, fov)
+    pipe = DeviceInputPipeline(dev, seq_len=S, custom_fov=fov, flip=flip)
+    pk = pipe.pack(images, clouds, radars, gps, beam, addresses)
+    torch.cuda.synchronize()
+    img = pk.images.cpu().numpy().reshape(B, S, 256, 256, 4)
+    lid = pk.lidars.cpu().numpy().reshape(B, S, 256, 256, 4)
+    rad = pk.radars.cpu().numpy().reshape(B, S, 256, 256, 4)
+    for b in range(B):
+        for t in range(S):
+            want = dr.image_to_input(images[t][b], flip)                      # (3,256,256) fp32
+            assert np.array_equal(img[b, t, :, :, :3], want.transpose(1, 2, 0)), (b, t)
+            assert not img[b, t, :, :, 3].any()
+            wl = dr.lidar_bev(clouds[t][b], addresses[b], fov, flip)[0].astype(np.float32)  # the fp32 cast of Engine.train
+            assert np.array_equal(lid[b, t, :, :, 0], wl), (b, t)
+            assert not lid[b, t, :, :, 1:].any()
+            wr = radars[t][b][:, :, ::-1] if flip else radars[t][b]
+            assert np.array_equal(rad[b, t, :, :, :2], wr.transpose(1, 2, 0))
+        wb, wi = dr.soft_beam_target(int(beam[b]), flip)
+        assert np.array_equal(pk.target[b].cpu().numpy(), wb.astype(np.float32)), b
+        assert int(pk.beamidx[b]) == wi
+    g = gps.astype(np.float32).copy()
+    if flip:
+        g[:, :, 1] = -g[:, :, 1]
+    assert np.array_equal(pk.gps.cpu().numpy(), g)
+    # the scratch histogram was left zeroed for the next batch, and a second pack gives the same result
+    assert int(pipe._counts.abs().sum()) == 0
+    pk2 = pipe.pack(images, clouds, radars, gps, beam, addresses)
+    assert torch.equal(pk2.lidars, pk.lidars) and torch.equal(pk2.images, pk.images)
+
+
+def test_raw_counts_and_histogram_semantics(dev):
+    """integer cell counts (before the clip) equal np.histogramdd, including points on bin edges, on the outer edges,
+    just outside, NaN / inf, an empty cloud and > 2^16 hits in one cell"""
+    from deepsense6g_tii_amd._lib import lib
+    from oracle import data_ref as dr
+    xb, yb = dr.fov_edges("scenario32", True)
+    c0 = dr.make_cloud(50000, 3, xb, yb)
+    c1 = np.zeros((0, 3))
+    c2 = np.tile(np.array([[-30.0, -10.0, 0.0]]), (70000, 1))
+    c2[:7] = [[xb[0], yb[0], 0], [xb[-1], yb[-1], 0], [xb[9], yb[200], 0], [np.nextafter(xb[-1], 1), 0, 0],
+              [np.nan, 0, 0], [-10.0, np.inf, 0], [-10.0, -np.inf, 0]]
+    clouds = [c0, c1, c2]
+    offs = np.zeros(4, dtype=np.int64)
+    offs[1:] = np.cumsum([len(c) for c in clouds])
+    pts = torch.from_numpy(np.concatenate(clouds)).to(dev)
+    offd = torch.from_numpy(offs).to(dev)
+    xe, ye = torch.from_numpy(xb).to(dev), torch.from_numpy(yb).to(dev)
+    counts = torch.zeros((3, 256, 256), dtype=torch.int32, device=dev)
+    lib().lidar_bev_count(pts.data_ptr(), 3, offd.data_ptr(), 3, int(offs[-1]), xe.data_ptr(), ye.data_ptr(), 0, 256,
+                          counts.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    got = counts.cpu().numpy().astype(np.int64)
+    for i, c in enumerate(clouds):
+        assert np.array_equal(got[i], dr.lidar_counts(c, xb, yb)), i
+    assert got[2].max() == 70000 - 7 and got[1].sum() == 0
+
+
+def test_model_accepts_packed_inputs(dev):
+    """TransFuser.forward(PackedInputs) == forward(lists of NCHW fp32 frames) bit for bit (same kernels after the pack)"""
+    from deepsense6g_tii_amd.data import DeviceInputPipeline
+    from deepsense6g_tii_amd.model import GlobalConfig, TransFuser
+    from oracle import data_ref as dr
+    B, S = 2, 5
+    addresses, images, clouds, radars, gps, beam = _mk(B, S, 11, False)
+    model = TransFuser(GlobalConfig(n_layer=1), dev).eval()
+    pk = DeviceInputPipeline(dev, seq_len=S).pack(images, clouds, radars, gps, beam, addresses)
+    with torch.no_grad():
+        out_packed = model(pk)
+        fronts = [torch.from_numpy(np.ascontiguousarray(im.transpose(0, 3, 1, 2))) for im in images]  # uint8 CHW
+        lidars = [torch.from_numpy(np.stack([dr.lidar_bev(c)[0][None] for c in clouds[t]])) for t in range(S)]  # fp64
+        rads = [torch.from_numpy(r) for r in radars]
+        out_lists = model(fronts, lidars, rads, torch.from_numpy(gps))
+    assert out_packed.shape == (B, 64)
+    assert torch.equal(out_packed, out_lists)
+    # training path: loss / backward through the packed batch
+    model.train()
+    loss, logits = model.train_step_loss(pk, None, None, None, pk.target)
+    assert torch.isfinite(loss).all() and model.join[4].weight.grad is not None
