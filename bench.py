@@ -79,58 +79,33 @@ def cpu_baseline(batch, steps):
 
 
 class IgemmTimer:
-    """Brackets every implicit-GEMM launch of one step with HIP events on the launch stream."""
+    """Live per-kernel timing of one step: the library brackets every implicit-GEMM KERNEL launch with HIP events on
+    its launch stream (ds6g_profile_begin/end), so the durations are the kernels' own (the split-K reduction that
+    follows a wgrad is not included) and line up with the rocprofv3 --kernel-trace averages under profiles/."""
 
-    def __init__(self):
-        self.records = []  # (variant, flops, ev0, ev1)
+    CAP = 1 << 14
 
     def install(self):
-        from deepsense6g_tii_amd import ops
         from deepsense6g_tii_amd._lib import lib
-        L = lib()
-        self._orig = {}
-        timer = self
-
-        def wrap(name, flops_fn):
-            orig = getattr(L, name)
-            self._orig[name] = orig
-
-            def call(*a):
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-                orig(*a)
-                e1.record()
-                timer.records.append((L.last_igemm_variant(), flops_fn(a), e0, e1))
-            setattr(L, name, call)
-
-        def conv_flops(a):  # (x, w, y, N, H, W, C, K, R, S, stride, pad, ...)
-            N, H, W, C, K, R, S, st, pad = a[3:12]
-            Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - S) // st + 1
-            return 2.0 * N * Ho * Wo * K * R * S * C
-
-        wrap("conv2d_fwd", conv_flops)
-        wrap("conv2d_dgrad", conv_flops)
-        wrap("conv2d_wgrad", conv_flops)
-        wrap("linear_fwd", lambda a: 2.0 * a[4] * a[5] * a[6])
-        wrap("linear_dgrad", lambda a: 2.0 * a[3] * a[4] * a[5])
-        wrap("linear_wgrad", lambda a: 2.0 * a[4] * a[5] * a[6])  # (x, dy, dw, dbias, M, N, K, ...)
-
-    def uninstall(self):
-        from deepsense6g_tii_amd._lib import lib
-        for name, orig in self._orig.items():
-            setattr(lib(), name, orig)
+        lib().profile_begin(self.CAP)
 
     def summary(self):
-        torch.cuda.synchronize()
+        import ctypes
+        from deepsense6g_tii_amd._lib import lib
+        var = (ctypes.c_int * self.CAP)()
+        fl = (ctypes.c_double * self.CAP)()
+        ms = (ctypes.c_float * self.CAP)()
+        n = lib().profile_end(var, fl, ms, self.CAP)
         agg = {}
-        for var, fl, e0, e1 in self.records:
-            ms = e0.elapsed_time(e1)
-            d = agg.setdefault(var, [0, 0.0, 0.0])
+        for i in range(n):
+            d = agg.setdefault(var[i], [0, 0.0, 0.0])
             d[0] += 1
-            d[1] += fl
-            d[2] += ms
+            d[1] += fl[i]
+            d[2] += ms[i]
         return agg
+
+    def uninstall(self):
+        pass
 
 
 def main():
@@ -220,16 +195,17 @@ def main():
         if not os.path.exists(path):
             return None
         ks = json.load(open(path))["kernels"]
-        bm, bn = VARIANT_NAMES[variant % 10].split("x")
-        pref = f"igemm_kernel<{variant % 100 // 10}, {bm}, {bn}, "
-        sel = [v for k, v in ks.items() if k.startswith(pref)]
-        n = sum(v["launches"] for v in sel)
-        return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n if n else None
+        v = ks.get(vname(variant))
+        return v["hbm_bytes_per_launch"] if v else None
 
     def vname(v, short=False):
-        # ds6g_last_igemm_variant(): 100 * uniform-walk + 10 * mode + tile
-        mode, tile, walk = MODE_NAMES[v % 100 // 10], VARIANT_NAMES[v % 10], ("" if v >= 100 else "/general-walk")
-        return f"{mode}/{tile}{walk}" if short else f"igemm_kernel<{mode},{tile}{walk}>"
+        # variant code (include/ds6g.h): 1000 * epilogue + 100 * uniform-walk + 10 * mode + tile  ->  the template
+        # instantiation exactly as rocprofv3 names it: igemm_kernel<mode, BM, BN, epilogue, 16, bf16, walk>
+        epi, walk, mode, tile = v // 1000, v % 1000 // 100, v % 100 // 10, v % 10
+        bm, bn = VARIANT_NAMES[tile].split("x")
+        if short:
+            return f"{MODE_NAMES[mode]}/{bm}x{bn}" + ("/epi" if epi else "") + ("" if walk else "/general-walk")
+        return f"igemm_kernel<{mode}, {bm}, {bn}, {epi}, 16, {1 if args.dtype == 'bf16' else 0}, {walk}>"
 
     if agg:
         dom = max(agg, key=lambda v: agg[v][2])

@@ -20,6 +20,7 @@
 // ds_read_b128.  Row-contiguous sources (both wgrad operands, dgrad weights) use a k-major [16][rows]
 // image: whole 256/512-B rows per wave-instruction and 8 conflict-free ds_read_b32 per fragment.
 #include "common.h"
+#include <vector>
 
 namespace {
 
@@ -586,8 +587,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *o = s;
 }
 
-// last launched variant, for the bench's live per-kernel timing: mode * 10 + {0: 128x128, 1: 128x64, 2: 64x64}
+// last launched variant, for the bench's live per-kernel timing (see ds6g_last_igemm_variant in the header)
 int g_last_variant = -1;
+
+// bench instrumentation: HIP events around every implicit-GEMM kernel launch, on the launch stream (ds6g_profile_*)
+struct ProfRec { int variant; double flops; hipEvent_t e0, e1; };
+std::vector<ProfRec>* g_prof = nullptr;
+size_t g_prof_cap = 0;
 int g_dbg = 0;
 
 // tile choice: 0 = 128x128, 1 = 128x64, 2 = 64x64 - the largest tile that still yields >= 384 workgroups
@@ -638,6 +644,16 @@ int launch_igemm(IgemmParams& p, int splits, int tile, hipStream_t st) {
     // BK = 32 was measured (tools/bench_igemm.py): within +-5 % on fwd/dgrad, 10-30 % slower on wgrad -> BK = 16
     const bool fast = fast_walk_ok<MODE>(p) && !(g_dbg & 0x80);
     const bool epi = MODE != MODE_WGRAD && full;
+    ProfRec* rec = nullptr;
+    if (g_prof && g_prof->size() < g_prof_cap) {
+        g_prof->push_back(ProfRec{});
+        rec = &g_prof->back();
+        rec->variant = 1000 * (int)epi + 100 * (int)fast + 10 * MODE + tile;
+        rec->flops = 2.0 * p.Mg * p.Ng * p.Kg;
+        (void)hipEventCreate(&rec->e0);
+        (void)hipEventCreate(&rec->e1);
+        (void)hipEventRecord(rec->e0, st);
+    }
     if (g_ds6g_bf16) {
         if (fast) { if (epi) launch_tile<MODE, 1, 16, 1, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 1, 1>(p, splits, tile, st); }
         else      { if (epi) launch_tile<MODE, 1, 16, 1, 0>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 1, 0>(p, splits, tile, st); }
@@ -645,7 +661,8 @@ int launch_igemm(IgemmParams& p, int splits, int tile, hipStream_t st) {
         if (fast) { if (epi) launch_tile<MODE, 1, 16, 0, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 0, 1>(p, splits, tile, st); }
         else      { if (epi) launch_tile<MODE, 1, 16, 0, 0>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 0, 0>(p, splits, tile, st); }
     }
-    g_last_variant = MODE * 10 + tile + (fast ? 100 : 0);
+    if (rec) (void)hipEventRecord(rec->e1, st);
+    g_last_variant = 1000 * (int)epi + 100 * (int)fast + 10 * MODE + tile;
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }
@@ -726,6 +743,32 @@ ConvBytes conv_bytes(const IgemmParams& p) {
 extern "C" {
 
 int ds6g_last_igemm_variant(void) { return g_last_variant; }
+
+int ds6g_profile_begin(int max_records) {
+    if (max_records <= 0) return DS6G_ERR_ARG;
+    if (!g_prof) g_prof = new std::vector<ProfRec>();
+    for (auto& r : *g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_prof->clear();
+    g_prof->reserve((size_t)max_records);
+    g_prof_cap = (size_t)max_records;
+    return DS6G_OK;
+}
+
+int ds6g_profile_end(int* variants, double* flops, float* ms, int cap) {
+    if (!g_prof) return 0;
+    int n = 0;
+    for (auto& r : *g_prof) {
+        (void)hipEventSynchronize(r.e1);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, r.e0, r.e1);
+        if (n < cap && variants && flops && ms) { variants[n] = r.variant; flops[n] = r.flops; ms[n] = t; ++n; }
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_prof->clear();
+    g_prof_cap = 0;
+    return n;
+}
 int ds6g_set_debug_flags(int flags) {
     g_dbg = flags & 0xbf;  // 0x80: force the general (FAST 0) walk
     g_wgrad_tile = (flags & 0x40) ? 2 : 1;

@@ -23,10 +23,17 @@ extern "C" {
 #endif
 
 int ds6g_version(void);
-/* which implicit-GEMM instantiation the last conv/linear call launched: 100*walk + 10*mode + tile
- * (walk 1 = wave-uniform k walk, 0 = general walk; mode 0 fwd, 1 dgrad, 2 wgrad; tile 0 128x128, 1 128x64,
- * 2 64x64).  Bench instrumentation only. */
+/* which implicit-GEMM instantiation the last conv/linear call launched: 1000*epilogue + 100*walk + 10*mode + tile
+ * (epilogue 1 = fused bias/ReLU/dropout/residual epilogue, 0 = plain store; walk 1 = wave-uniform k walk, 0 = general
+ * walk; mode 0 fwd, 1 dgrad, 2 wgrad; tile 0 128x128, 1 128x64, 2 64x64), i.e. the template arguments of
+ * igemm_kernel<mode, BM, BN, epilogue, 16, bf16, walk> as rocprofv3 prints them.  Bench instrumentation only. */
 int ds6g_last_igemm_variant(void);
+/* bench instrumentation: between profile_begin and profile_end every implicit-GEMM KERNEL launch (not the split-K
+ * reduction that may follow it) is bracketed by HIP events on its launch stream.  profile_end synchronises and returns
+ * the number of records written to the three arrays (variant code as above, GEMM flops 2*M*N*K as launched, elapsed
+ * milliseconds).  Not thread-safe; bench.py only. */
+int ds6g_profile_begin(int max_records);
+int ds6g_profile_end(int* variants, double* flops, float* ms, int cap);
 /* ablation switches for kernel timing experiments (results become wrong); 0 = normal operation */
 int ds6g_set_debug_flags(int flags);
 /* matrix-core mode of the conv / linear / attention kernels (process-wide): 0 (default) = exact fp32 MFMA, the parity
