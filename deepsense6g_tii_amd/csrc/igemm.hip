@@ -529,34 +529,60 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         }
         return;
     }
+    if (!(MODE == MODE_DGRAD && p.hstep != 1)) {
+        // full epilogue with the same branch-free addressing: mask, residual and output all have the output's
+        // [Mg][Ng] shape, so ONE 32-bit byte offset serves every per-element tensor and out-of-tile rows / columns fall
+        // off the buffer descriptors (loads return 0, stores are dropped)
+        const unsigned nbytes = (unsigned)p.Mg * (unsigned)p.Ng * 4u;
+        const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, nbytes, 0x00020000);
+        const auto m_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask_src ? p.mask_src : outp), 0, nbytes, 0x00020000);
+        const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual ? p.residual : outp), 0, nbytes, 0x00020000);
+        const unsigned rowbytes = (unsigned)p.Ng * 4u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+                const int row0 = m0 + wm * (BM / 2) + i * 32 + 4 * khalf;
+                const bool cok = col < p.Ng;
+                const float bias = (p.bias && cok) ? p.bias[col] : 0.f;
+                const unsigned base = cok ? (unsigned)row0 * rowbytes + (unsigned)col * 4u : OOB_OFF;
+                const unsigned e0 = (unsigned)row0 * (unsigned)p.Ng + (unsigned)col;  // element index (dropout counter)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned dr = (unsigned)((r & 3) + 8 * (r >> 2));
+                    const unsigned off = base + dr * rowbytes;
+                    float v = acc[i][j][r] + bias;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.mask_src) v = (__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, off, 0, 0)) > 0.f) ? v : 0.f;
+                    if (p.drop_thr)
+                        v = ds6g_keep(p.seed, p.seed_off + (uint64_t)(e0 + dr * (unsigned)p.Ng), p.drop_thr) ? v * p.drop_scale : 0.f;
+                    if (p.residual) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, off, 0, 0));
+                    if (p.accumulate) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(o_rsrc, off, 0, 0));
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, off, 0, 0);
+                }
+            }
+        }
+        return;
+    }
+    // strided dgrad: rows of the parity-class sub-grid scatter to full-resolution pixels
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
             if (col >= p.Ng) continue;
-            const float bias = (MODE != MODE_WGRAD && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 if (row >= p.Mg) continue;
-                size_t orow = (size_t)row;
-                if (MODE == MODE_DGRAD && p.hstep != 1) {  // parity-class sub-grid -> full-resolution pixel
-                    const int ww = row % p.Ws;
-                    const int t = row / p.Ws;
-                    const int hh = t % p.Hs;
-                    orow = ((size_t)(t / p.Hs) * p.H + p.h0 + hh * p.hstep) * p.W + p.w0 + ww * p.wstep;
-                }
+                const int ww = row % p.Ws;
+                const int t = row / p.Ws;
+                const int hh = t % p.Hs;
+                const size_t orow = ((size_t)(t / p.Hs) * p.H + p.h0 + hh * p.hstep) * p.W + p.w0 + ww * p.wstep;
                 const size_t o = orow * p.Ng + col;
                 float v = acc[i][j][r];
-                if (MODE != MODE_WGRAD) {
-                    v += bias;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.mask_src) v = (p.mask_src[o] > 0.f) ? v : 0.f;
-                    if (p.drop_thr) v = ds6g_keep(p.seed, p.seed_off + o, p.drop_thr) ? v * p.drop_scale : 0.f;
-                    if (p.residual) v += p.residual[o];
-                    if (p.accumulate) v += outp[o];
-                }
+                if (p.accumulate) v += outp[o];
                 outp[o] = v;
             }
         }
