@@ -208,6 +208,8 @@ class TransFuser(nn.Module):
         self._ws_side = {}
         self._side_streams = None
         self.multi_stream = True  # run the three (independent) trunks on three HIP streams between fusion points
+        self.overlap_wgrad = True  # GPT-stage weight gradients on a second stream, overlapping the dgrad / attention chain
+        self._wg_side, self._wg_keep = None, []
         self.fuse_qkv = True      # key|query|value projections as one GEMM when their parameters are contiguous (arena)
         self._anchor = None
         self._arena = None
@@ -682,7 +684,20 @@ class TransFuser(nn.Module):
     def _lin_param_grads(self, lin, x, dy):
         gw, aw = self._g(lin.weight)
         gb, ab = self._g(lin.bias)
-        ops.linear_wgrad(x, dy, gw, self._ws, accumulate=bool(aw), dbias_ptr=gb)
+        self._linear_wgrad(x, dy, gw, bool(aw), gb)
+
+    def _linear_wgrad(self, x, dy, gw, accumulate, gb):
+        """Weight / bias gradient of a Linear.  Inside a GPT stage's backward (one stream, a serial chain of dgrad /
+        attention / LayerNorm kernels) the weight gradients feed nothing but the optimizer, so they are launched on an
+        otherwise idle trunk stream and overlap the chain; x and dy are kept alive until the stage joins."""
+        side = self._wg_side
+        if side is None:
+            ops.linear_wgrad(x, dy, gw, self._ws, accumulate=accumulate, dbias_ptr=gb)
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.linear_wgrad(x, dy, gw, self._ws, accumulate=accumulate, dbias_ptr=gb)
+        self._wg_keep.append((x, dy))
 
     def _block_bwd(self, blk, ctx, dout, need_dx=True):
         x, c1, a1, s1, c2, s2, cd, sd, out = ctx
@@ -730,7 +745,7 @@ class TransFuser(nn.Module):
             dkqv = torch.empty((dy.shape[0], 3 * C), dtype=F32, device=dy.device)
             ops.attention_bwd(q, k, v, y, dy, lse, B, T, nh, self._ws, pa, self._seed, off_a,
                               out=(dkqv[:, C:2 * C], dkqv[:, :C], dkqv[:, 2 * C:]))
-            ops.linear_wgrad(h, dkqv, fg[0], self._ws, accumulate=bool(self._g(at.key.weight)[1]), dbias_ptr=fg[1])
+            self._linear_wgrad(h, dkqv, fg[0], bool(self._g(at.key.weight)[1]), fg[1])
             dh = ops.linear_dgrad(dkqv, fw[0], C)
         else:
             dq, dk, dv = ops.attention_bwd(q, k, v, y, dy, lse, B, T, nh, self._ws, pa, self._seed, off_a)
@@ -764,8 +779,17 @@ class TransFuser(nn.Module):
         gfw, af = self._g(gpt.ln_f.weight)
         gfb, _ = self._g(gpt.ln_f.bias)
         dx = ops.layernorm_bwd(dxo, x_last, mf, rf, self._w(gpt.ln_f.weight), gfw, gfb, self._ws, accumulate=bool(af))
+        if self.multi_stream and self.overlap_wgrad:
+            if self._side_streams is None:
+                self._fork()
+                self._join()
+            self._wg_side = self._side_streams[0]
         for blk, bc in zip(reversed(list(gpt.blocks)), reversed(blk_ctx)):
             dx = self._gpt_block_bwd(blk, bc, dx, B, T)
+        if self._wg_side is not None:
+            torch.cuda.current_stream().wait_stream(self._wg_side)
+            self._wg_side = None
+            self._wg_keep = []
         dpre = ops.dropout(dx, pe, self._seed, off_e) if pe > 0 else dx
         gpos, apos = self._g(gpt.pos_emb)
         L.batch_sum(dpre.data_ptr(), gpos, T * C, B, T * C, apos, st)
