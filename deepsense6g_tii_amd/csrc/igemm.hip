@@ -22,6 +22,16 @@
 #include "common.h"
 #include <vector>
 
+// LDS stages of the k loop (DMA runs STAGES-1 k-tiles ahead).  Measured on gfx950 (tools/bench_igemm.py): fwd / dgrad
+// gain 2-11 % from a third stage (more bytes in flight per CU outweigh 8 -> 6 resident workgroups), wgrad (128x64
+// tiles, 12 KB per stage) loses 1-3 %.
+#ifndef IGEMM_STAGES_FD
+#define IGEMM_STAGES_FD 3
+#endif
+#ifndef IGEMM_STAGES_W
+#define IGEMM_STAGES_W 2
+#endif
+
 namespace {
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
@@ -86,6 +96,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     __shared__ __attribute__((aligned(16))) float As1[BM * BK];
     __shared__ __attribute__((aligned(16))) float Bs0[BN * BK];
     __shared__ __attribute__((aligned(16))) float Bs1[BN * BK];
+    constexpr int NS = (MODE == MODE_WGRAD) ? IGEMM_STAGES_W : IGEMM_STAGES_FD;
+    static_assert(NS >= 2 && NS <= 4, "2..4 LDS stages");
+    __shared__ __attribute__((aligned(16))) float As2[NS >= 3 ? BM * BK : 4];
+    __shared__ __attribute__((aligned(16))) float Bs2[NS >= 3 ? BN * BK : 4];
+    __shared__ __attribute__((aligned(16))) float As3[NS >= 4 ? BM * BK : 4];
+    __shared__ __attribute__((aligned(16))) float Bs3[NS >= 4 ? BN * BK : 4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -416,8 +432,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     // one k-tile: start the DMA of the next tile into (An, Bn), multiply the tile resident in (Ac, Bc)
     float csum = 0.f;  // WGRAD bias gradient: column sum of the dy tile, owned by thread tid < BM of tile_n == 0 blocks
     const bool do_csum = (MODE == MODE_WGRAD) && p.want_colsum && tile_n == 0 && tid < BM;
-    auto k_step = [&](const float* Ac, const float* Bc, float* An, float* Bn, bool more) {
-        if (more && !(p.dbg & 1)) issue_tiles(An, Bn);
+    // NS >= 3 stages, DMA NS-1 k-tiles ahead: wait for THIS tile only (younger ones may still be in flight), barrier
+    // (everyone has this tile and is done with the previous one), refill the previous tile's stage, multiply.
+    // rem = k-tiles after this one.  NS == 2: issue the next tile, multiply, wait + barrier at the end.
+    auto k_step = [&](const float* Ac, const float* Bc, float* An, float* Bn, int rem) {
+        if (NS >= 3) {
+            if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (A_LD + B_LD)) : "memory");
+            else if (rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(p.dbg & 4)) __syncthreads();
+        }
+        if (rem >= NS - 1 && !(p.dbg & 1)) issue_tiles(An, Bn);
         if (MODE == MODE_WGRAD && do_csum) {
 #pragma unroll
             for (int k = 0; k < BK; ++k) csum += Ac[k * BM + tid];
@@ -487,16 +512,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         // the current buffers before the DMA after next overwrites them.  sched_barrier pins the wait BEHIND the
         // MFMA chain (an asm wait does not order register-only instructions) so the DMA flies under the MFMAs.
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(p.dbg & 4)) __syncthreads();
+        if (NS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(p.dbg & 4)) __syncthreads();
+        }
     };
 
-    if (nk > 0 && !(p.dbg & 16)) issue_tiles(As0, Bs0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        k_step(As0, Bs0, As1, Bs1, kt + 1 < nk);
-        if (kt + 1 < nk) k_step(As1, Bs1, As0, Bs0, kt + 2 < nk);
+    float* const Ast[4] = {As0, As1, As2, As3};
+    float* const Bst[4] = {Bs0, Bs1, Bs2, Bs3};
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u)
+        if (u < nk && !(p.dbg & 16)) issue_tiles(Ast[u], Bst[u]);
+    if (NS == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (int kt0 = 0; kt0 < nk; kt0 += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int kt = kt0 + u;
+            if (kt < nk) k_step(Ast[u], Bst[u], Ast[(u + NS - 1) % NS], Bst[(u + NS - 1) % NS], nk - 1 - kt);
+        }
     }
 
     // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ---------
