@@ -22,6 +22,8 @@ LIN = [("bal768", 12288, 1024, 512), ("bal768k4096", 12288, 1024, 4096), ("bal15
        ("gpt4_fc2", 11544, 512, 2048)]
 reps = int(os.environ.get("REPS", "5"))
 only = os.environ.get("ONLY")
+if os.environ.get("ZERO"):  # all-zero operands: same instruction stream, minimal data toggling (power experiment)
+    torch.randn = lambda *a, **k: torch.zeros(*a, **{kk: vv for kk, vv in k.items() if kk != "generator"})
 lib().set_debug_flags(int(os.environ.get("DBG", "0")))
 lib().set_compute_mode(int(os.environ.get("BF16", "0")))
 
