@@ -191,6 +191,7 @@ class _FusionFn(torch.autograd.Function):
 
 class TransFuser(nn.Module):
     """Drop-in for model2_seq.TransFuser (GPT variant).  See module docstring."""
+    _GRU_HEAD = False
 
     def __init__(self, config, device, pretrain_weight=False):
         super().__init__()
@@ -200,6 +201,11 @@ class TransFuser(nn.Module):
         self.encoder = Encoder(config)
         self.join = nn.Sequential(nn.Linear(512, 256), nn.ReLU(inplace=True), nn.Linear(256, 128),
                                   nn.ReLU(inplace=True), nn.Linear(128, 64))
+        # the 30->5 variant (model2_seq_30to5.py:842-843) appends an autoregressive GRU head; TransFuser30to5 sets this
+        self.gru_head = bool(getattr(config, "gru_head", False)) or self._GRU_HEAD
+        if self.gru_head:
+            self.decoder = nn.GRUCell(input_size=64, hidden_size=64)
+            self.output = nn.Linear(64, 64)
         if pretrain_weight:
             self.load_pretrained_weight()
         self._seed = 0x5DEECE66D
@@ -229,7 +235,7 @@ class TransFuser(nn.Module):
         gradients always form ONE contiguous, growing prefix of the gradient arena: data-parallel
         all-reduce buckets are plain slices of it (no packing copy) and can start while earlier
         layers are still being differentiated."""
-        if name.startswith("join."):
+        if name.startswith(("join.", "decoder.", "output.")):
             return 0
         for s in (4, 3, 2, 1):
             if f"transformer{s}." in name or f"vel_emb{s}." in name:
@@ -665,9 +671,20 @@ class TransFuser(nn.Module):
         L.small_linear_fwd(fused.data_ptr(), self._w(j0.weight), self._w(j0.bias), h1.data_ptr(), B, 256, 512, B, 0, 1, st)
         L.small_linear_fwd(h1.data_ptr(), self._w(j2.weight), self._w(j2.bias), h2.data_ptr(), B, 128, 256, B, 0, 1, st)
         L.small_linear_fwd(h2.data_ptr(), self._w(j4.weight), self._w(j4.bias), logits.data_ptr(), B, 64, 128, B, 0, 0, st)
+        gru = None
+        if self.gru_head:  # model2_seq_30to5.py:846-862: logits is the GRU's initial hidden state
+            T = self.pred_len
+            pred = torch.empty((B, T, 64), dtype=F32, device=self.device)
+            saved = torch.empty(L.gru_head_saved_floats(B, T), dtype=F32, device=self.device) if record else None
+            d = self.decoder
+            L.gru_head_fwd(logits.data_ptr(), self._w(d.weight_ih), self._w(d.weight_hh), self._w(d.bias_ih),
+                           self._w(d.bias_hh), self._w(self.output.weight), self._w(self.output.bias), pred.data_ptr(),
+                           0 if saved is None else saved.data_ptr(), B, T, 64, st)
+            gru = (logits, saved)
+            logits = pred
         tape = None
         if record:
-            tape = (B, stem_ctx, layer_ctx, stage_ctx, (fused, h1, h2, [f.shape for f in feats]), gps)
+            tape = (B, stem_ctx, layer_ctx, stage_ctx, (fused, h1, h2, [f.shape for f in feats], gru), gps)
         return logits, tape
 
     # ================================================================ backward walk =============
@@ -850,8 +867,24 @@ class TransFuser(nn.Module):
         st = ops._stream()
         cfg = self.config
         B, stem_ctx, layer_ctx, stage_ctx, head, gps = tape
-        fused, h1, h2, fshapes = head
+        fused, h1, h2, fshapes, gru = head
         self._begin_backward()
+        if gru is not None:  # back through the GRU head: dpred (B, pred_len, 64) -> gradient of the join output
+            z0, saved = gru
+            T = self.pred_len
+            assert dlogits.shape == (B, T, 64) and dlogits.dtype == F32
+            npar = L.gru_head_slab_floats()
+            slabs = torch.empty((B, npar), dtype=F32, device=self.device)
+            dz = torch.empty((B, 64), dtype=F32, device=self.device)
+            d = self.decoder
+            L.gru_head_bwd(dlogits.contiguous().data_ptr(), z0.data_ptr(), saved.data_ptr(), self._w(d.weight_ih),
+                           self._w(d.weight_hh), self._w(self.output.weight), dz.data_ptr(), slabs.data_ptr(), B, T, 64, st)
+            off = 0
+            for prm in (d.weight_ih, d.weight_hh, d.bias_ih, d.bias_hh, self.output.weight, self.output.bias):
+                gp, acc = self._g(prm)
+                L.batch_sum(slabs.data_ptr() + 4 * off, gp, prm.numel(), B, npar, acc, st)
+                off += prm.numel()
+            dlogits = dz
         assert dlogits.shape == (B, 64) and dlogits.dtype == F32
         S = cfg.seq_len
         j0, j2, j4 = self.join[0], self.join[2], self.join[4]
@@ -897,3 +930,11 @@ class TransFuser(nn.Module):
             self._milestone_done(2 + 2 * (4 - s))
         self._milestone_done(9)
         self._end_backward()
+
+
+class TransFuser30to5(TransFuser):
+    """Drop-in for /root/reference/model2_seq_30to5.py::TransFuser (:831-862) with the GPT encoder: the same fusion
+    path at ``config.seq_len`` = 10 (1922 tokens) followed by ``decoder = nn.GRUCell(64, 64)`` / ``output =
+    nn.Linear(64, 64)`` unrolled ``config.pred_len`` (5) times; ``forward`` returns (B, pred_len, 64)."""
+    _GRU_HEAD = True
+

@@ -121,6 +121,20 @@ int ds6g_lidar_bev_finish(unsigned* counts, float* dst, int B, int nbins, int Cd
 int ds6g_soft_beam_target(const int* beamidx, float* target, int* beamidx_out, int B, int nbeams, int flip,
                           void* stream);
 
+/* ---- gru.hip : autoregressive GRU beam-sequence head of the 30->5 variant, model2_seq_30to5.py:842-862:
+ * x = 0, h = h0 (the join output); T times: h = GRUCell(x, h); x = x + Linear(h); pred[:, t] = x.  H must be 64.
+ * w_ih / w_hh: [3H][H] (gate rows r, z, n as in nn.GRUCell), b_ih / b_hh: [3H], w_out: [H][H], b_out: [H].
+ * saved: B*T*6*H floats (gru_head_saved_floats) written by fwd for bwd, or NULL for inference.
+ * bwd writes dh0 [B][H] and one parameter-gradient slab per sample (gru_head_slab_floats each, laid out dW_ih, dW_hh,
+ * db_ih, db_hh, dW_out, db_out); sum the slabs over the batch with ds6g_batch_sum. */
+size_t ds6g_gru_head_saved_floats(int B, int T);
+size_t ds6g_gru_head_slab_floats(void);
+int ds6g_gru_head_fwd(const float* h0, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                      const float* w_out, const float* b_out, float* pred, float* saved, int B, int T, int H,
+                      void* stream);
+int ds6g_gru_head_bwd(const float* dpred, const float* h0, const float* saved, const float* w_ih, const float* w_hh,
+                      const float* w_out, float* dh0, float* slabs, int B, int T, int H, void* stream);
+
 /* ---- spatial.hip -------------------------------------------------------------------------------*/
 /* normalize_imagenet + stack + NCHW->NHWC: model2_seq.py:36-45,481-482,491-493 */
 int ds6g_pack_input(const float* src, float* dst, int B, int Cs, int H, int W, int Cd, int frames_per_sample, int t,

@@ -49,6 +49,7 @@ class RefConfig:
     resid_pdrop: float = 0.1
     add_velocity: int = 1
     pred_len: int = 4
+    gru_head: bool = False  # the 30->5 variant's GRU beam-sequence head (model2_seq_30to5.py:842-862)
 
     @property
     def n_tokens(self) -> int:  # model2_seq.py:189
@@ -131,6 +132,13 @@ def param_shapes(cfg: RefConfig) -> "OrderedDict[str, tuple]":
     for idx, (o, i) in zip((0, 2, 4), ((256, 512), (128, 256), (64, 128))):
         out[f"join.{idx}.weight"] = (o, i)
         out[f"join.{idx}.bias"] = (o,)
+    if cfg.gru_head:  # nn.GRUCell(64, 64) + nn.Linear(64, 64), model2_seq_30to5.py:842-843
+        out["decoder.weight_ih"] = (192, 64)
+        out["decoder.weight_hh"] = (192, 64)
+        out["decoder.bias_ih"] = (192,)
+        out["decoder.bias_hh"] = (192,)
+        out["output.weight"] = (64, 64)
+        out["output.bias"] = (64,)
     return out
 
 
@@ -186,7 +194,9 @@ def make_state(cfg: RefConfig, seed: int = 0, scheme: str = "test") -> "OrderedD
                 t = 0.02 * torch.randn(shape, generator=g)
             else:
                 t = torch.zeros(shape) if scheme == "init" else 0.02 * torch.randn(shape, generator=g)
-        else:  # vel_emb / join: torch Linear default U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+        elif name.startswith("decoder."):  # nn.GRUCell default: U(-1/sqrt(hidden), 1/sqrt(hidden)) for all four tensors
+            t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(64)
+        else:  # vel_emb / join / output: torch Linear default U(-1/sqrt(fan_in), 1/sqrt(fan_in))
             fan_in = shape[1] if name.endswith("weight") else None
             if fan_in is None:
                 wshape = param_shapes(cfg)[name[: -len("bias")] + "weight"]
@@ -409,7 +419,31 @@ def join_forward(sd, fused):
     return F.linear(h, sd["join.4.weight"], sd["join.4.bias"])
 
 
+def gru_head_forward(sd, z, pred_len):
+    """The autoregressive beam-sequence head of model2_seq_30to5.py:846-862: x = 0, hidden = z (the join output);
+    pred_len times: hidden = GRUCell(x, hidden); x = x + output(hidden); collect x  ->  (B, pred_len, 64).
+    GRUCell is written out (torch.nn.GRUCell documentation: r, z, n gate order); tests pin it against nn.GRUCell."""
+    w_ih, w_hh, b_ih, b_hh = (sd["decoder." + k] for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+    x = torch.zeros((z.shape[0], 64), dtype=z.dtype)
+    h = z
+    out = []
+    for _ in range(pred_len):
+        gi = F.linear(x, w_ih, b_ih)
+        gh = F.linear(h, w_hh, b_hh)
+        i_r, i_z, i_n = gi.chunk(3, 1)
+        h_r, h_z, h_n = gh.chunk(3, 1)
+        r = torch.sigmoid(i_r + h_r)
+        u = torch.sigmoid(i_z + h_z)
+        n = torch.tanh(i_n + r * h_n)
+        h = (1 - u) * n + u * h
+        x = F.linear(h, sd["output.weight"], sd["output.bias"]) + x
+        out.append(x)
+    return torch.stack(out, dim=1)
+
+
 def transfuser_forward(sd, image_list, lidar_list, radar_list, gps, cfg: RefConfig, ctx: Ctx | None = None):
-    """TransFuser.forward (model2_seq.py:880-894) with the GPT ``Encoder`` wired in (:860)."""
+    """TransFuser.forward (model2_seq.py:880-894) with the GPT ``Encoder`` wired in (:860); with cfg.gru_head the
+    forward of model2_seq_30to5.py:846-862 (same encoder + join, then the GRU head)."""
     ctx = ctx or Ctx()
-    return join_forward(sd, encoder_forward(sd, image_list, lidar_list, radar_list, gps, cfg, ctx))
+    z = join_forward(sd, encoder_forward(sd, image_list, lidar_list, radar_list, gps, cfg, ctx))
+    return gru_head_forward(sd, z, cfg.pred_len) if cfg.gru_head else z
