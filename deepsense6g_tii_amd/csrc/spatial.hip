@@ -235,39 +235,64 @@ __global__ __launch_bounds__(256) void upsample_add_fwd_kernel(const float* __re
     *reinterpret_cast<f32x4*>(out + i * 4) = *reinterpret_cast<const f32x4*>(feat + i * 4) + up;
 }
 
-// dtok[row(f,ph,pw)][c] = sum_{h,w} wh(h,ph) ww(w,pw) dout[f,h,w,c]   (adjoint of the upsample)
+// dtok[row(f,ph,pw)][c] = sum_{h,w} wh(h,ph) ww(w,pw) dout[f,h,w,c]   (adjoint of the upsample).
+// One workgroup per token cell (f, ph, pw): the <= 4k x 4k window of contributing pixels (k = H/8) is split over
+// 256 / (C/4) row slices, the 1-D bilinear weights are tabulated once per workgroup, partial sums meet in LDS.
+constexpr int UPB_MAXWIN = 64;  // window rows / columns per cell (4 * H/8, H <= 128)
 __global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const float* __restrict__ dout,
                                                                float* __restrict__ dtok, int N, int H, int C, int fps,
                                                                int mod_off, int T) {
-    const int cg = C >> 2;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)N * 64 * cg) return;
-    const int c4 = (int)(i % cg) * 4;
-    long t = i / cg;
-    const int hw = (int)(t & 63);
-    const int f = (int)(t >> 6);
+    __shared__ float whs[UPB_MAXWIN], wws[UPB_MAXWIN];
+    __shared__ f32x4 part[256];
+    const int cg = C >> 2;                      // float4 channel groups
+    const int lanes_c = cg < 256 ? cg : 256;    // threads along channels
+    const int slices = 256 / lanes_c;           // row slices of the window
+    const int f = blockIdx.x >> 6, hw = blockIdx.x & 63;
     const int ph = hw >> 3, pw = hw & 7;
     const int k = H >> 3;
     const float inv = 8.0f / (float)H;
-    const int hlo = max(0, (ph - 1) * k - k), hhi = min(H, (ph + 2) * k + k);
-    const int wlo = max(0, (pw - 1) * k - k), whi = min(H, (pw + 2) * k + k);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int h = hlo; h < hhi; ++h) {
-        int h0, h1;
-        float lh;
-        bilin_src(h, inv, 8, h0, h1, lh);
-        const float wh = (h0 == ph ? 1.f - lh : 0.f) + (h1 == ph ? lh : 0.f);
-        if (wh == 0.f) continue;
-        for (int w = wlo; w < whi; ++w) {
-            int w0, w1;
-            float lw;
-            bilin_src(w, inv, 8, w0, w1, lw);
-            const float ww = (w0 == pw ? 1.f - lw : 0.f) + (w1 == pw ? lw : 0.f);
-            if (ww == 0.f) continue;
-            acc += (wh * ww) * *reinterpret_cast<const f32x4*>(dout + (((long)f * H + h) * H + w) * C + c4);
+    const int hlo = max(0, (ph - 2) * k), hhi = min(H, (ph + 3) * k);
+    const int wlo = max(0, (pw - 2) * k), whi = min(H, (pw + 3) * k);
+    const int tid = threadIdx.x;
+    if (tid < UPB_MAXWIN) {
+        int i0, i1;
+        float l;
+        float a = 0.f, b2 = 0.f;
+        if (hlo + tid < hhi) {
+            bilin_src(hlo + tid, inv, 8, i0, i1, l);
+            a = (i0 == ph ? 1.f - l : 0.f) + (i1 == ph ? l : 0.f);
         }
+        if (wlo + tid < whi) {
+            bilin_src(wlo + tid, inv, 8, i0, i1, l);
+            b2 = (i0 == pw ? 1.f - l : 0.f) + (i1 == pw ? l : 0.f);
+        }
+        whs[tid] = a;
+        wws[tid] = b2;
     }
-    *reinterpret_cast<f32x4*>(dtok + tok_row(f, fps, mod_off, T, hw) * C + c4) = acc;
+    __syncthreads();
+    const int lc = tid % lanes_c, sl = tid / lanes_c;
+    for (int c0 = 0; c0 < cg; c0 += lanes_c) {  // one pass unless C > 1024
+        const int c4 = (c0 + lc) * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (sl < slices && c0 + lc < cg) {
+            for (int h = hlo + sl; h < hhi; h += slices) {
+                const float wh = whs[h - hlo];
+                if (wh == 0.f) continue;
+                const float* row = dout + (((long)f * H + h) * H) * C + c4;
+                for (int w = wlo; w < whi; ++w) {
+                    const float ww = wws[w - wlo];
+                    if (ww != 0.f) acc += (wh * ww) * *reinterpret_cast<const f32x4*>(row + (long)w * C);
+                }
+            }
+        }
+        part[tid] = acc;
+        __syncthreads();
+        if (sl == 0 && c0 + lc < cg) {
+            for (int s2 = 1; s2 < slices; ++s2) acc += part[s2 * lanes_c + lc];
+            *reinterpret_cast<f32x4*>(dtok + tok_row(f, fps, mod_off, T, hw) * C + c4) = acc;
+        }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -469,9 +494,9 @@ int ds6g_upsample_add_fwd(const float* feat, const float* tokens, float* out, in
 int ds6g_upsample_add_bwd(const float* dout, float* dtok, int N, int H, int C, int frames_per_sample, int mod_off,
                           int T, void* stream) {
     DS6G_ENTER();
-    DS6G_CHECK_ARG(dout && dtok && C % 4 == 0 && H % 8 == 0);
-    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid1((long)N * 64 * (C / 4))), dim3(256), 0, (hipStream_t)stream,
-                       dout, dtok, N, H, C, frames_per_sample, mod_off, T);
+    DS6G_CHECK_ARG(dout && dtok && C % 4 == 0 && H % 8 == 0 && 5 * (H / 8) <= UPB_MAXWIN && N > 0);
+    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(N * 64), dim3(256), 0, (hipStream_t)stream, dout, dtok, N, H, C,
+                       frames_per_sample, mod_off, T);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }

@@ -92,12 +92,31 @@ __global__ void small_linear_dgrad_kernel(const float* __restrict__ dy, const fl
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * K) return;
     const int k = i % K, m = i / K;
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) {
-        float g = dy[(long)m * N + n];
-        if (y_mask && !(y_mask[(long)m * N + n] > 0.f)) g = 0.f;
-        s = fmaf(g, w[(long)n * K + k], s);
+    // few threads (M*K) and a long reduction: four independent chains, eight loads each in flight
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float* dyr = dy + (long)m * N;
+    const float* mkr = y_mask ? y_mask + (long)m * N : nullptr;
+    int n = 0;
+#pragma unroll 2
+    for (; n + 4 <= N; n += 4) {
+        float g0 = dyr[n], g1 = dyr[n + 1], g2 = dyr[n + 2], g3 = dyr[n + 3];
+        if (mkr) {
+            if (!(mkr[n] > 0.f)) g0 = 0.f;
+            if (!(mkr[n + 1] > 0.f)) g1 = 0.f;
+            if (!(mkr[n + 2] > 0.f)) g2 = 0.f;
+            if (!(mkr[n + 3] > 0.f)) g3 = 0.f;
+        }
+        s0 = fmaf(g0, w[(long)n * K + k], s0);
+        s1 = fmaf(g1, w[(long)(n + 1) * K + k], s1);
+        s2 = fmaf(g2, w[(long)(n + 2) * K + k], s2);
+        s3 = fmaf(g3, w[(long)(n + 3) * K + k], s3);
     }
+    for (; n < N; ++n) {
+        float g = dyr[n];
+        if (mkr && !(mkr[n] > 0.f)) g = 0.f;
+        s0 = fmaf(g, w[(long)n * K + k], s0);
+    }
+    const float s = (s0 + s1) + (s2 + s3);
     float* d = dx + (long)(m / rpg) * gstride + (long)(m % rpg) * K + k;
     *d = accumulate ? *d + s : s;
 }
