@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="matrix-core mode: f32 = exact fp32 MFMA (parity path, default); bf16 = operands rounded to bf16, "
                          "fp32 accumulate/storage (BASELINE configs[1]-style throughput configuration)")
+    ap.add_argument("--image-only", action="store_true",
+                    help="BASELINE configs[1]: zeroed LiDAR / radar inputs - the reference's own 'zerolike' missing-modality "
+                         "semantics (mambafuser_seq.py:384-391); same kernels and FLOPs, other input statistics")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the three trunks on one stream (per-kernel profiling: durations are not overlapped)")
     ap.add_argument("--cpu-batch", type=int, default=12)
@@ -154,6 +157,9 @@ def main():
         reducer = ddist.attach(model, opt)
     fronts, lidars, radars, gps, target, _ = make_batch(args.batch, cfg.seq_len, cfg.n_views, cfg.add_velocity,
                                                         seed=100 + rank, device=dev)
+    if args.image_only:
+        lidars = [torch.zeros_like(t) for t in lidars]
+        radars = [torch.zeros_like(t) for t in radars]
     batch = (fronts, lidars, radars, gps, target)
 
     def sync():
@@ -231,7 +237,7 @@ def main():
         samples = args.batch * world * args.steps
         value = samples / elapsed
         out = {
-            "metric": "training samples/sec (5-frame seq, bs=12 per GPU)",
+            "metric": f"training samples/sec (5-frame seq, bs={args.batch} per GPU)",
             "value": value,
             "unit": "samples/s",
             "n_gpus": world,
@@ -243,8 +249,10 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: full camera+LiDAR+radar+GPS fusion, 5x(3+1+2)x256x256 + 2x2 "
-                                   "GPS per sample, bs=12 per GPU, sigmoid focal loss, AdamW, train-mode BN, dropout 0.1",
+            "config": {"workload": ("BASELINE configs[1]: image-only (LiDAR / radar inputs zeroed), " if args.image_only else
+                                    "BASELINE configs[2]: full camera+LiDAR+radar+GPS fusion, ") +
+                                   f"5x(3+1+2)x256x256 + 2x2 GPS per sample, bs={args.batch} per GPU, sigmoid focal loss, "
+                                   "AdamW, train-mode BN, dropout 0.1",
                        "global_batch": args.batch * world, "seq_len": cfg.seq_len,
                        "parallelism": f"dp{world}", "ema": bool(args.ema)},
             "loss": final_loss,
