@@ -251,6 +251,22 @@ def test_other_sequence_lengths_and_ragged_batch(dev, seq_len, batch, n_layer):
         assert ((g - sdo[name].grad).norm() / sdo[name].grad.norm()).item() < 5e-2, name
 
 
+@pytest.mark.parametrize("kw_extra", [dict(n_views=2), dict(add_velocity=0)])
+def test_config_variants_n_views_and_radar_channels(dev, kw_extra):
+    """config.n_views = 2 (two camera frames per time step: pos_emb / token layout of model2_seq.py:189,261-263 with
+    (n_views + 2) * seq_len * 64 + 2 tokens) and add_velocity = 0 (one radar channel, model2_seq.py:417-420)."""
+    from oracle import fusion_ref as fr
+    kw = dict(seq_len=2, n_layer=1, embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0, **kw_extra)
+    model, rcfg, sd = _build(dev, kw, seed=23)
+    imgs, lids, rads, gps, target, _ = fr.make_inputs(rcfg, 2, seed=34)
+    assert len(imgs) == rcfg.n_views * rcfg.seq_len and rads[0].shape[1] == (2 if rcfg.add_velocity else 1)
+    model.train()
+    loss, logits = model.train_step_loss(imgs, lids, rads, gps, target)
+    ref = fr.transfuser_forward(sd, imgs, lids, rads, gps, rcfg, fr.Ctx(training=True))
+    assert rel(logits, ref) < TOL
+    assert torch.isfinite(loss).all()
+
+
 def test_fused_qkv_equals_separate_projections(dev):
     """The arena lays key|query|value out as one [3C, C] block and the model runs them as one GEMM; switching the
     fusion off (three GEMMs, the general path used when parameters were re-pointed) must give the same logits and
