@@ -589,12 +589,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                     const unsigned dr = (unsigned)((r & 3) + 8 * (r >> 2));
                     const unsigned off = base + dr * rowbytes;
                     float v = acc[i][j][r] + bias;
-                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.relu == 1) v = fmaxf(v, 0.f);
                     if (p.mask_src) v = (__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, off, 0, 0)) > 0.f) ? v : 0.f;
                     if (p.drop_thr)
                         v = ds6g_keep(p.seed, p.seed_off + (uint64_t)(e0 + dr * (unsigned)p.Ng), p.drop_thr) ? v * p.drop_scale : 0.f;
                     if (p.residual) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, off, 0, 0));
                     if (p.accumulate) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(o_rsrc, off, 0, 0));
+                    if (p.relu == 2) v = fmaxf(v, 0.f);  // activation after the residual add (BasicBlock tail)
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, off, 0, 0);
                 }
             }
@@ -894,6 +895,22 @@ int ds6g_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
     p.a_bytes = (unsigned)cb.y; p.b_bytes = (unsigned)cb.x;
     p.Mg = K; p.Ng = R * S * C; p.Kg = N * p.Ho * p.Wo;
     return run_wgrad(p, dw, accumulate, nullptr, 0, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// inference form of Conv2d + eval-mode BatchNorm2d (+ residual) (+ ReLU) with the BN folded into w / bias
+// (ds6g_bn_fold): y = act(conv(x, w) + bias [+ residual]);  relu: 0 none, 1 before the residual add, 2 after it
+int ds6g_conv2d_bias_act_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, int N,
+                             int H, int W, int C, int K, int R, int S, int stride, int pad, int relu, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && w && y && C % 4 == 0 && N > 0 && relu >= 0 && relu <= 2);
+    IgemmParams p;
+    fill_conv(p, N, H, W, C, K, R, S, stride, pad);
+    p.a_src = x; p.b_src = w; p.out = y; p.bias = bias; p.residual = residual; p.relu = relu;
+    const ConvBytes cb = conv_bytes(p);
+    DS6G_CHECK_ARG(cb.ok);
+    p.a_bytes = (unsigned)cb.x; p.b_bytes = (unsigned)cb.w;
+    p.Mg = N * p.Ho * p.Wo; p.Ng = K; p.Kg = R * S * C;
+    return launch_igemm<MODE_FWD>(p, (hipStream_t)stream);
 }
 
 // y[M][N] = residual + dropout( act( x[M][K] @ w[N][K]^T + bias ) )

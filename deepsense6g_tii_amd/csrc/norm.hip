@@ -372,6 +372,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     }
 }
 
+// eval-mode BatchNorm folded into the preceding convolution: w_out[o][j] = w[o][j] * g[o] / sqrt(var[o] + eps),
+// bias_out[o] = b[o] - mean[o] * g[o] / sqrt(var[o] + eps).  cin < cout_pad zero-pads each tap (stem: 3/1/2 -> 4 ch).
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ mean,
+                                                      const float* __restrict__ var, float eps, float* __restrict__ w_out,
+                                                      float* __restrict__ bias_out, int K, int taps, int cin, int cpad) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per_o = (long)taps * cpad;
+    if (i >= (long)K * per_o) return;
+    const int o = (int)(i / per_o);
+    const int rem = (int)(i - (long)o * per_o);
+    const int tap = rem / cpad, c = rem - tap * cpad;
+    const float scale = gamma[o] / sqrtf(var[o] + eps);
+    w_out[i] = c < cin ? w[((long)o * taps + tap) * cin + c] * scale : 0.f;
+    if (rem == 0) bias_out[o] = beta[o] - mean[o] * scale;
+}
+
 }  // namespace
 
 extern "C" {
@@ -514,6 +531,19 @@ int ds6g_colsum(const float* x, long M, int C, float* out, int accumulate, void*
     DS6G_LAUNCH_CHECK();
     hipLaunchKernelGGL(col_finalize_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, out,
                        out, C, accumulate);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+int ds6g_bn_fold(const float* w, const float* gamma, const float* beta, const float* running_mean,
+                 const float* running_var, float eps, float* w_out, float* bias_out, int K, int taps, int cin, int cpad,
+                 void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(w && gamma && beta && running_mean && running_var && w_out && bias_out && K > 0 && taps > 0 &&
+                   cin > 0 && cpad >= cin);
+    const long n = (long)K * taps * cpad;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, gamma, beta,
+                       running_mean, running_var, eps, w_out, bias_out, K, taps, cin, cpad);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }

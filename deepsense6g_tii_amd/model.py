@@ -217,6 +217,8 @@ class TransFuser(nn.Module):
         self.overlap_wgrad = True  # GPT-stage weight gradients on a second stream, overlapping the dgrad / attention chain
         self._wg_map, self._wg_used, self._wg_keep = {}, {}, []
         self.overlap_wgrad_trunks = False  # measured: no gain on top of the three concurrent trunk streams
+        self._fold_now = False
+        self.fold_bn_eval = True  # eval(): BatchNorm folded into the conv weights (no BN kernels at inference)
         self.fuse_qkv = True      # key|query|value projections as one GEMM when their parameters are contiguous (arena)
         self._anchor = None
         self._arena = None
@@ -491,10 +493,15 @@ class TransFuser(nn.Module):
             for t, f in enumerate(frames):
                 assert f.shape == (B, cin, H, W), (f.shape, (B, cin, H, W))
                 L.pack_input(f.data_ptr(), x.data_ptr(), B, cin, H, W, 4, S, t, int(normalize), st)
-        wpad = torch.empty((64, 7, 7, 4), dtype=F32, device=self.device)
-        L.pad_channels(self._w(trunk.conv1.weight), wpad.data_ptr(), 64 * 49, cin, 4, 0, 0, st)
-        c1 = ops.conv2d_fwd(x, wpad.data_ptr(), 64, 7, 7, 2, 3)
-        a1, st1 = self._bn_fwd(trunk.bn1, c1, True, None, train)
+        if self._fold_now:
+            wf, bf = ops.bn_fold(self._w(trunk.conv1.weight), trunk.bn1, 64, 49, cin, 4)  # folds and pads to 4 channels
+            c1, st1 = None, None
+            a1 = ops.conv2d_bias_act_fwd(x, wf.data_ptr(), bf.data_ptr(), 64, 7, 7, 2, 3, relu=1)
+        else:
+            wpad = torch.empty((64, 7, 7, 4), dtype=F32, device=self.device)
+            L.pad_channels(self._w(trunk.conv1.weight), wpad.data_ptr(), 64 * 49, cin, 4, 0, 0, st)
+            c1 = ops.conv2d_fwd(x, wpad.data_ptr(), 64, 7, 7, 2, 3)
+            a1, st1 = self._bn_fwd(trunk.bn1, c1, True, None, train)
         N, H1, W1, _ = a1.shape
         Ho, Wo = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
         p1 = torch.empty((N, Ho, Wo, 64), dtype=F32, device=self.device)
@@ -504,6 +511,19 @@ class TransFuser(nn.Module):
 
     def _block_fwd(self, blk, x, train):
         K = blk.conv1.out_channels
+        if self._fold_now:
+            # inference: eval-mode BN is an affine map per channel - folded into the conv weights, the block is three
+            # (two) convolutions with bias / ReLU / identity epilogues and no BN pass at all
+            Cin = x.shape[-1]
+            w1, b1 = ops.bn_fold(self._w(blk.conv1.weight), blk.bn1, K, 9, Cin)
+            a1 = ops.conv2d_bias_act_fwd(x, w1.data_ptr(), b1.data_ptr(), K, 3, 3, blk.stride, 1, relu=1)
+            idn = x
+            if blk.downsample is not None:
+                wd, bd = ops.bn_fold(self._w(blk.downsample[0].weight), blk.downsample[1], K, 1, Cin)
+                idn = ops.conv2d_bias_act_fwd(x, wd.data_ptr(), bd.data_ptr(), K, 1, 1, blk.stride, 0, relu=0)
+            w2, b2 = ops.bn_fold(self._w(blk.conv2.weight), blk.bn2, K, 9, K)
+            out = ops.conv2d_bias_act_fwd(a1, w2.data_ptr(), b2.data_ptr(), K, 3, 3, 1, 1, relu=2, residual=idn)
+            return out, None
         c1 = ops.conv2d_fwd(x, self._w(blk.conv1.weight), K, 3, 3, blk.stride, 1)
         a1, s1 = self._bn_fwd(blk.bn1, c1, True, None, train)
         c2 = ops.conv2d_fwd(a1, self._w(blk.conv2.weight), K, 3, 3, 1, 1)
@@ -601,6 +621,7 @@ class TransFuser(nn.Module):
         st = ops._stream()
         cfg = self.config
         train = self.training
+        self._fold_now = self.fold_bn_eval and not train and not record  # inference only: backward needs the BN tape
         S = cfg.seq_len
         if torch.is_tensor(lidars):
             B = lidars.shape[0] // S

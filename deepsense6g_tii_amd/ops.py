@@ -55,6 +55,30 @@ def conv2d_fwd(x, w_ohwi_ptr, K, R, S, stride, pad, out=None):
     return y
 
 
+def conv2d_bias_act_fwd(x, w_ohwi_ptr, bias_ptr, K, R, S, stride, pad, relu=0, residual=None):
+    """inference conv with folded BN: act(conv(x, w) + bias [+ residual]); relu 0 none / 1 before / 2 after the add"""
+    N, H, W, C = x.shape
+    _chk(x)
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    y = torch.empty((N, Ho, Wo, K), dtype=F32, device=x.device)
+    if residual is not None:
+        _chk(residual, N, Ho, Wo, K)
+    lib().conv2d_bias_act_fwd(_p(x), w_ohwi_ptr, bias_ptr, _p(residual), _p(y), N, H, W, C, K, R, S, stride, pad,
+                              int(relu), _stream())
+    return y
+
+
+def bn_fold(w_ohwi_ptr, bn, K, taps, cin, cpad=None):
+    """-> (w_folded [K, taps, cpad], bias [K]) of an eval-mode BatchNorm2d folded into the preceding conv"""
+    cpad = cin if cpad is None else cpad
+    dev = bn.weight.device
+    w_out = torch.empty((K, taps, cpad), dtype=F32, device=dev)
+    b_out = torch.empty((K,), dtype=F32, device=dev)
+    lib().bn_fold(w_ohwi_ptr, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                  bn.running_var.data_ptr(), float(bn.eps), w_out.data_ptr(), b_out.data_ptr(), K, taps, cin, cpad, _stream())
+    return w_out, b_out
+
+
 def conv2d_dgrad(dy, w_ohwi_ptr, x_shape, R, S, stride, pad, out=None, accumulate=False):
     N, H, W, C = x_shape
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)

@@ -51,6 +51,17 @@ int ds6g_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
                       int stride, int pad, int accumulate, void* stream);
 int ds6g_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
                       int stride, int pad, int accumulate, float* ws, size_t ws_bytes, void* stream);
+/* inference form of Conv2d + eval-mode BatchNorm2d (+ identity) (+ ReLU) of the torchvision BasicBlock / stem
+ * (call sites model2_seq.py:495-512,528-530,546-548,565-567 under model.eval(), train2_seq.py:161): the BN is folded
+ * into w / bias by ds6g_bn_fold, y = act(conv(x, w) + bias [+ residual]); relu: 0 none, 1 before the residual add,
+ * 2 after it. */
+int ds6g_conv2d_bias_act_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, int N,
+                             int H, int W, int C, int K, int R, int S, int stride, int pad, int relu, void* stream);
+/* w_out[o][tap][c] = w[o][tap][c] * gamma[o]/sqrt(running_var[o]+eps) (c >= cin: zero padding up to cpad channels),
+ * bias_out[o] = beta[o] - running_mean[o] * gamma[o]/sqrt(running_var[o]+eps);  w: [K][taps][cin] (OHWI). */
+int ds6g_bn_fold(const float* w, const float* gamma, const float* beta, const float* running_mean,
+                 const float* running_var, float eps, float* w_out, float* bias_out, int K, int taps, int cin, int cpad,
+                 void* stream);
 /* nn.Linear of the GPT blocks with fused epilogue y = residual + dropout(act(x w^T + b)):
  * model2_seq.py:97-99 (q,k,v), :109 (proj + resid_drop), :121-126 (MLP, ReLU), :131-132 (residuals). */
 int ds6g_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int relu,

@@ -295,3 +295,25 @@ def test_fused_qkv_equals_separate_projections(dev):
               "encoder.transformer2.blocks.0.attn.value.weight", "encoder.image_encoder.features.conv1.weight"):
         d = (g0[n] - g1[n]).norm().item() / (g1[n].norm().item() + 1e-20)
         assert d < 5e-3, (n, d)
+
+
+def test_eval_bn_folding_matches_unfolded(dev):
+    """model.eval(): BatchNorm folded into the conv weights (conv + bias / ReLU / identity epilogues, no BN kernels)
+    must equal the unfolded eval path (bn_eval_prepare + bn_apply) to fp32 rounding, after running statistics have
+    moved away from their initial values."""
+    from oracle import fusion_ref as fr
+    kw = dict(n_layer=1, embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
+    model, rcfg, sd = _build(dev, kw, seed=31)
+    imgs, lids, rads, gps, target, _ = fr.make_inputs(rcfg, 2, seed=35)
+    model.train()
+    model.train_step_loss(imgs, lids, rads, gps, target)   # updates the BN running statistics
+    model.eval()
+    with torch.no_grad():
+        model.fold_bn_eval = True
+        a = model(imgs, lids, rads, gps)
+        model.fold_bn_eval = False
+        b = model(imgs, lids, rads, gps)
+    assert rel(a, b) < 2e-5
+    ref = fr.transfuser_forward({k: v.cpu() for k, v in model.state_dict().items()}, imgs, lids, rads, gps, rcfg,
+                                fr.Ctx(training=False))
+    assert rel(a, ref) < TOL
