@@ -44,8 +44,9 @@ extern int g_ds6g_bf16;
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Counter-based dropout RNG: keep(idx) is a pure function of (seed, idx), so backward kernels
-// regenerate the mask instead of storing it.  Two rounds of a 32-bit integer finalizer over the
-// 64-bit counter mixed with the seed.
+// regenerate the mask instead of storing it.  One round of a 32-bit integer finalizer (lowbias32) over the low
+// counter word, keyed by the seed and the high counter word (the attention kernels evaluate it T*T times per head
+// in each of their three passes, so its instruction count is visible in the step time).
 __host__ __device__ __forceinline__ uint32_t ds6g_hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU;
     x ^= x >> 15; x *= 0x846ca68bU;
@@ -53,11 +54,9 @@ __host__ __device__ __forceinline__ uint32_t ds6g_hash32(uint32_t x) {
     return x;
 }
 __host__ __device__ __forceinline__ uint32_t ds6g_rand_u32(uint64_t seed, uint64_t idx) {
-    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-    uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
-    uint32_t h = ds6g_hash32(lo ^ s0);
-    h = ds6g_hash32(h ^ hi ^ (s1 * 0x9E3779B9U) ^ 0x85ebca6bU);
-    return h;
+    const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    const uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85ebca6bU);  // uniform per launch
+    return ds6g_hash32(lo ^ key ^ (hi * 0x9E3779B9U));
 }
 // threshold = floor(p * 2^32); element is DROPPED when rand < threshold.
 __host__ __device__ __forceinline__ bool ds6g_keep(uint64_t seed, uint64_t idx, uint32_t threshold) {
