@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     __shared__ __attribute__((aligned(16))) float As1[BM * BK];
     __shared__ __attribute__((aligned(16))) float Bs0[BN * BK];
     __shared__ __attribute__((aligned(16))) float Bs1[BN * BK];
-    constexpr int NS = (MODE == MODE_WGRAD) ? IGEMM_STAGES_W : IGEMM_STAGES_FD;
+    constexpr int NS = (MODE == MODE_WGRAD) ? IGEMM_STAGES_W : (BK == 32 ? 2 : IGEMM_STAGES_FD);
     static_assert(NS >= 2 && NS <= 4, "2..4 LDS stages");
     __shared__ __attribute__((aligned(16))) float As2[NS >= 3 ? BM * BK : 4];
     __shared__ __attribute__((aligned(16))) float Bs2[NS >= 3 ? BN * BK : 4];
@@ -483,21 +483,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         // its use and exposes the LDS latency once per k-step)
         __builtin_amdgcn_sched_barrier(0);
         if (BF) {
-            static_assert(!BF || BK == 16, "one 32x32x16 bf16 MFMA per k-tile: lane half h holds k = 8h..8h+7");
-            bf16x8 a8[TM], b8[TN];
+            // one 32x32x16 bf16 MFMA per 16 tile columns: in MFMA q lane half h supplies its fragment values 8q..8q+7
+            // (tile columns KH*h + 8q ..), the same column set for both operands
+            static_assert(!BF || BK % 16 == 0, "bf16 k-tiles are multiples of 16");
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int q = 0; q < BK / 16; ++q) {
+                bf16x8 a8[TM], b8[TN];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a8[i][e] = (__bf16)af[i][e];
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) b8[j][e] = (__bf16)bf[j][e];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int e = 0; e < 8; ++e) a8[i][e] = (__bf16)af[i][8 * q + e];
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) b8[j][e] = (__bf16)bf[j][8 * q + e];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+            }
         } else {
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
@@ -662,6 +667,7 @@ int g_dbg = 0;
 // tile choice: 0 = 128x128, 1 = 128x64, 2 = 64x64 - the largest tile that still yields >= 384 workgroups
 int g_min_blocks = 2560;  // measured: many small (64x64, 8 waves/SIMD) workgroups beat larger tiles up to here
 int g_wgrad_tile = 1;
+int g_bf16_bk32 = 1;
 int pick_tile(int Mg, int Ng, long splits) {
     const long t128 = (long)cdiv(Mg, 128) * cdiv(Ng, 128) * splits;
     const long t12864 = (long)cdiv(Mg, 128) * cdiv(Ng, 64) * splits;
@@ -690,9 +696,9 @@ void launch_tile(IgemmParams& p, int splits, int tile, hipStream_t st) {
 
 // FAST walk eligibility (see igemm_kernel); also fills wg_rows for WGRAD
 template <int MODE>
-bool fast_walk_ok(IgemmParams& p) {
-    if (MODE == MODE_FWD) return p.C % 16 == 0;
-    if (MODE == MODE_DGRAD) return p.K % 16 == 0;
+bool fast_walk_ok(IgemmParams& p, int bk = 16) {
+    if (MODE == MODE_FWD) return p.C % bk == 0;
+    if (MODE == MODE_DGRAD) return p.K % bk == 0;
     // WGRAD: the 16 pixels of a k-tile share one (image, output row) - or cover whole rows of one image
     if (p.Wo % 16 == 0 || p.N * p.Ho == 1) { p.wg_rows = 0; return true; }
     if (16 % p.Wo == 0 && p.Ho % (16 / p.Wo) == 0) { p.wg_rows = 16 / p.Wo; return true; }
@@ -717,7 +723,14 @@ int launch_igemm(IgemmParams& p, int splits, int tile, hipStream_t st) {
         (void)hipEventCreate(&rec->e1);
         (void)hipEventRecord(rec->e0, st);
     }
-    if (g_ds6g_bf16) {
+    // bf16 mode: one MFMA per 16 columns makes the k-tile bookkeeping (DMA issue, barrier) the bottleneck - fwd / dgrad
+    // use 32-column k-tiles (two MFMAs per barrier) wherever the uniform walk allows it
+    const bool bk32 = g_ds6g_bf16 && g_bf16_bk32 && MODE != MODE_WGRAD && fast && fast_walk_ok<MODE>(p, 32);
+    if (bk32) {
+        if constexpr (MODE != MODE_WGRAD) {
+            if (epi) launch_tile<MODE, 1, 32, 1, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 32, 1, 1>(p, splits, tile, st);
+        }
+    } else if (g_ds6g_bf16) {
         if (fast) { if (epi) launch_tile<MODE, 1, 16, 1, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 1, 1>(p, splits, tile, st); }
         else      { if (epi) launch_tile<MODE, 1, 16, 1, 0>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 1, 0>(p, splits, tile, st); }
     } else {
@@ -834,8 +847,9 @@ int ds6g_profile_end(int* variants, double* flops, float* ms, int cap) {
 }
 int ds6g_set_debug_flags(int flags) {
     g_dbg = flags & 0xbf;  // 0x80: force the general (FAST 0) walk
+    g_bf16_bk32 = (flags & 0x10000000) ? 0 : 1;  // bf16 mode: 16-column k-tiles everywhere (A/B experiment)
     g_wgrad_tile = (flags & 0x40) ? 2 : 1;
-    if (flags >> 8) g_min_blocks = flags >> 8;
+    if ((flags >> 8) & 0xfffff) g_min_blocks = (flags >> 8) & 0xfffff;
     return 0;
 }
 
