@@ -699,9 +699,9 @@ template <int MODE>
 bool fast_walk_ok(IgemmParams& p, int bk = 16) {
     if (MODE == MODE_FWD) return p.C % bk == 0;
     if (MODE == MODE_DGRAD) return p.K % bk == 0;
-    // WGRAD: the 16 pixels of a k-tile share one (image, output row) - or cover whole rows of one image
-    if (p.Wo % 16 == 0 || p.N * p.Ho == 1) { p.wg_rows = 0; return true; }
-    if (16 % p.Wo == 0 && p.Ho % (16 / p.Wo) == 0) { p.wg_rows = 16 / p.Wo; return true; }
+    // WGRAD: the bk pixels of a k-tile share one (image, output row) - or cover whole rows of one image
+    if (p.Wo % bk == 0 || p.N * p.Ho == 1) { p.wg_rows = 0; return true; }
+    if (bk % p.Wo == 0 && p.Ho % (bk / p.Wo) == 0) { p.wg_rows = bk / p.Wo; return true; }
     return false;
 }
 
@@ -725,6 +725,7 @@ int launch_igemm(IgemmParams& p, int splits, int tile, hipStream_t st) {
     }
     // bf16 mode: one MFMA per 16 columns makes the k-tile bookkeeping (DMA issue, barrier) the bottleneck - fwd / dgrad
     // use 32-column k-tiles (two MFMAs per barrier) wherever the uniform walk allows it
+    // (wgrad was measured with 32-pixel k-tiles too: no gain, its k-major fragments are LDS-read bound)
     const bool bk32 = g_ds6g_bf16 && g_bf16_bk32 && MODE != MODE_WGRAD && fast && fast_walk_ok<MODE>(p, 32);
     if (bk32) {
         if constexpr (MODE != MODE_WGRAD) {
