@@ -668,6 +668,7 @@ int g_dbg = 0;
 int g_min_blocks = 2560;  // measured: many small (64x64, 8 waves/SIMD) workgroups beat larger tiles up to here
 int g_wgrad_tile = 1;
 int g_bf16_bk32 = 1;
+int g_f32_bk32 = 2;  // 0 never, 1 wherever the walk allows it (experiment), 2 small-spatial convs only
 int pick_tile(int Mg, int Ng, long splits) {
     const long t128 = (long)cdiv(Mg, 128) * cdiv(Ng, 128) * splits;
     const long t12864 = (long)cdiv(Mg, 128) * cdiv(Ng, 64) * splits;
@@ -730,6 +731,14 @@ int launch_igemm(IgemmParams& p, int splits, int tile, hipStream_t st) {
     if (bk32) {
         if constexpr (MODE != MODE_WGRAD) {
             if (epi) launch_tile<MODE, 1, 32, 1, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 32, 1, 1>(p, splits, tile, st);
+        }
+    } else if (!g_ds6g_bf16 && MODE != MODE_WGRAD && fast && fast_walk_ok<MODE>(p, 32) &&
+               (g_f32_bk32 == 1 || (g_f32_bk32 == 2 && !p.is_linear && p.R * p.S > 1 &&
+                                    (long)cdiv(p.Mg, 64) * cdiv(p.Ng, 64) <= 1024))) {
+        // fp32: 32-column k-tiles (two LDS stages) pay on the small-spatial conv layers (16x16, 8x8: few workgroups
+        // per CU, +4-15 %), not on the large ones or the GPT linears (measured, tools/bench_igemm.py)
+        if constexpr (MODE != MODE_WGRAD) {
+            if (epi) launch_tile<MODE, 1, 32, 0, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 32, 0, 1>(p, splits, tile, st);
         }
     } else if (g_ds6g_bf16) {
         if (fast) { if (epi) launch_tile<MODE, 1, 16, 1, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 1, 1>(p, splits, tile, st); }
@@ -848,7 +857,8 @@ int ds6g_profile_end(int* variants, double* flops, float* ms, int cap) {
 }
 int ds6g_set_debug_flags(int flags) {
     g_dbg = flags & 0xbf;  // 0x80: force the general (FAST 0) walk
-    g_bf16_bk32 = (flags & 0x10000000) ? 0 : 1;  // bf16 mode: 16-column k-tiles everywhere (A/B experiment)
+    g_bf16_bk32 = (flags & 0x10000000) ? 0 : 1;
+    g_f32_bk32 = (flags & 0x20000000) ? 1 : ((flags & 0x40000000) ? 0 : 2);   // fp32 32-column k-tiles: everywhere / never  // bf16 mode: 16-column k-tiles everywhere (A/B experiment)
     g_wgrad_tile = (flags & 0x40) ? 2 : 1;
     if ((flags >> 8) & 0xfffff) g_min_blocks = (flags >> 8) & 0xfffff;
     return 0;
