@@ -736,7 +736,7 @@ int launch_igemm(IgemmParams& p, int splits, int tile, hipStream_t st) {
                (g_f32_bk32 == 1 || (g_f32_bk32 == 2 && !p.is_linear && p.R * p.S > 1 &&
                                     (long)cdiv(p.Mg, 64) * cdiv(p.Ng, 64) <= 1024))) {
         // fp32: 32-column k-tiles (two LDS stages) pay on the small-spatial conv layers (16x16, 8x8: few workgroups
-        // per CU, +4-15 %), not on the large ones or the GPT linears (measured, tools/bench_igemm.py)
+        // per CU, +4-15 %), not on the large ones, the GPT linears or any wgrad (measured, tools/bench_igemm.py)
         if constexpr (MODE != MODE_WGRAD) {
             if (epi) launch_tile<MODE, 1, 32, 0, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 32, 0, 1>(p, splits, tile, st);
         }
