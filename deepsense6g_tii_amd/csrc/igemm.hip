@@ -56,6 +56,8 @@ struct IgemmParams {
     int k_per_split;     // multiple of 16
     size_t split_stride; // elements between split-K slabs
     int tiles_n;
+    int nclass;          // DGRAD: > 1 = parity classes of a strided conv in blockIdx.y (class params derived in-kernel)
+    double prof_flops;   // host-side only: flops of the launch for the profiler (0 = 2*Mg*Ng*Kg)
     int wg_rows;         // FAST WGRAD: 0 = a k-tile of 16 pixels stays inside one output row; else rows per k-tile (16 / Wo)
     int is_linear;       // host-side only: the problem is a Linear layer (split-K heuristics)
     int want_colsum;     // WGRAD: also emit column sums of the A operand (bias gradient) behind each slab
@@ -78,7 +80,22 @@ struct IgemmParams {
 // spends ~2 (FWD/DGRAD) to ~8 (WGRAD) VALU instructions per DMA piece instead of ~25.  FAST 0 is the general walk
 // (any channel count, any image size), kept for the stem (C = 4) and odd shapes.
 template <int MODE, int BM, int BN, int EPI, int BK, int BF, int FAST>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams pin) {
+    IgemmParams p = pin;
+    if (MODE == MODE_DGRAD && pin.nclass > 1) {
+        // strided dgrad: blockIdx.y = input-pixel parity class (ph, pw); class (ph, pw) only sees the taps
+        // r = (ph + pad) mod 2 (+2, ...), s likewise - all four classes of a layer run as ONE launch
+        const int ph = blockIdx.y >> 1, pw = blockIdx.y & 1;
+        p.h0 = ph;
+        p.w0 = pw;
+        p.r0 = (ph + p.pad) & 1;
+        p.nr = p.r0 < p.R ? (p.R - p.r0 + 1) / 2 : 0;
+        p.s0 = (pw + p.pad) & 1;
+        p.ns = p.s0 < p.S ? (p.S - p.s0 + 1) / 2 : 0;
+        p.Kg = p.nr * p.ns * p.K;
+        if (p.ns == 0) p.ns = 1;
+        if (p.Kg == 0 && p.accumulate) return;  // no tap hits this class: its pixels keep their value
+    }
     constexpr int CH = BK / 4;              // 16-B chunks per K-contiguous row
     constexpr int RPB = 16 / CH;            // rows per 256-B LDS bank row
     constexpr int KH = BK / 2;              // k values per lane half
@@ -680,17 +697,18 @@ int pick_tile(int Mg, int Ng, long splits) {
 template <int MODE, int EPI, int BKV, int BF, int FAST>
 void launch_tile(IgemmParams& p, int splits, int tile, hipStream_t st) {
     dim3 block(256);
+    const int ny = p.nclass > 1 ? p.nclass : 1;
     if (tile == 0) {
         p.tiles_n = cdiv(p.Ng, 128);
-        dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, 1, splits);
+        dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, ny, splits);
         hipLaunchKernelGGL((igemm_kernel<MODE, 128, 128, EPI, BKV, BF, FAST>), grid, block, 0, st, p);
     } else if (tile == 1) {
         p.tiles_n = cdiv(p.Ng, 64);
-        dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, 1, splits);
+        dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, ny, splits);
         hipLaunchKernelGGL((igemm_kernel<MODE, 128, 64, EPI, BKV, BF, FAST>), grid, block, 0, st, p);
     } else {
         p.tiles_n = cdiv(p.Ng, 64);
-        dim3 grid(cdiv(p.Mg, 64) * p.tiles_n, 1, splits);
+        dim3 grid(cdiv(p.Mg, 64) * p.tiles_n, ny, splits);
         hipLaunchKernelGGL((igemm_kernel<MODE, 64, 64, EPI, BKV, BF, FAST>), grid, block, 0, st, p);
     }
 }
@@ -719,7 +737,7 @@ int launch_igemm(IgemmParams& p, int splits, int tile, hipStream_t st) {
         g_prof->push_back(ProfRec{});
         rec = &g_prof->back();
         rec->variant = 1000 * (int)epi + 100 * (int)fast + 10 * MODE + tile;
-        rec->flops = 2.0 * p.Mg * p.Ng * p.Kg;
+        rec->flops = p.prof_flops > 0 ? p.prof_flops : 2.0 * p.Mg * p.Ng * p.Kg;
         (void)hipEventCreate(&rec->e0);
         (void)hipEventCreate(&rec->e1);
         (void)hipEventRecord(rec->e0, st);
@@ -889,20 +907,15 @@ int ds6g_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
     DS6G_CHECK_ARG(cb.ok);
     p.a_bytes = (unsigned)cb.y; p.b_bytes = (unsigned)cb.w;
     if (stride == 2 && H % 2 == 0 && W % 2 == 0) {
-        // four input-pixel parity classes; class (ph,pw) only sees taps r = (ph+pad) mod 2 (+2..), s likewise
-        for (int ph = 0; ph < 2; ++ph)
-            for (int pw = 0; pw < 2; ++pw) {
-                IgemmParams q = p;
-                q.h0 = ph; q.hstep = 2; q.Hs = H / 2; q.w0 = pw; q.wstep = 2; q.Ws = W / 2;
-                q.r0 = (ph + pad) & 1; q.rstep = 2; q.nr = q.r0 < R ? (R - q.r0 + 1) / 2 : 0;
-                q.s0 = (pw + pad) & 1; q.sstep = 2; q.ns = q.s0 < S ? (S - q.s0 + 1) / 2 : 0;
-                q.Mg = N * q.Hs * q.Ws; q.Ng = C; q.Kg = q.nr * q.ns * K;
-                if (q.ns == 0) q.ns = 1;  // Kg == 0: the launch only zero-fills (or keeps, when accumulating) its pixels
-                if (q.Kg == 0 && accumulate) continue;
-                int rc = launch_igemm<MODE_DGRAD>(q, (hipStream_t)stream);
-                if (rc) return rc;
-            }
-        return DS6G_OK;
+        // four input-pixel parity classes in blockIdx.y of ONE launch (class parameters are derived in the kernel);
+        // host-side values describe the largest class (tile choice, eligibility of the uniform walk)
+        IgemmParams q = p;
+        q.nclass = 4;
+        q.hstep = 2; q.Hs = H / 2; q.wstep = 2; q.Ws = W / 2; q.rstep = 2; q.sstep = 2;
+        q.h0 = 0; q.w0 = 0; q.r0 = 0; q.s0 = 0; q.nr = (R + 1) / 2; q.ns = (S + 1) / 2;
+        q.Mg = N * q.Hs * q.Ws; q.Ng = C; q.Kg = q.nr * q.ns * K;
+        q.prof_flops = 2.0 * q.Mg * q.Ng * (double)(R * S) * K;   // all taps are visited exactly once over the classes
+        return launch_igemm<MODE_DGRAD>(q, (hipStream_t)stream);
     }
     p.Mg = N * H * W; p.Ng = C; p.Kg = R * S * K;
     return launch_igemm<MODE_DGRAD>(p, (hipStream_t)stream);
