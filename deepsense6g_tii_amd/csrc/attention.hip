@@ -19,6 +19,8 @@
 // small second kernel (flash-decoding style for the forward: rescale by exp(m_s - m)).  Deterministic: no atomics.
 #include "common.h"
 
+int g_ds6g_attn_percu = 0;
+
 namespace {
 
 struct AttnParams {
@@ -548,6 +550,7 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 
 // number of loop splits: fills the chip evenly.  cap = workgroups resident at once (256 CUs x per-CU residency)
 int pick_splits(long base_blocks, int ntiles, int per_cu, int max_splits) {
+    if (g_ds6g_attn_percu > 0) per_cu = g_ds6g_attn_percu;  // timing experiments (ds6g_set_debug_flags bits 20-23)
     const long cap = 256L * per_cu;
     int best = 1;
     double best_cost = 1e30;
@@ -624,7 +627,7 @@ int ds6g_attention_fwd(const float* q, const float* k, const float* v, float* o,
     p.thr = ds6g_drop_threshold(drop_p); p.dscale = 1.f / (1.f - drop_p); p.seed = seed; p.seed_off = seed_off;
     const int ntiles = cdiv(T, 32);
     const int qblocks = cdiv(T, 128);
-    const int per_cu = hd >= 128 ? 2 : 3;
+    const int per_cu = 3;  // measured (tools/bench_attn.py, DBG bits 20-23): 3 is best or tied for every head dim
     const size_t max_by_ws = ws ? ws_bytes / (slab * sizeof(float) + (size_t)B * nh * T * 2 * sizeof(float)) : 1;
     int splits = pick_splits((long)qblocks * nh * B, ntiles, per_cu, (int)(max_by_ws < 8 ? max_by_ws : 8));
     if (splits < 1) splits = 1;

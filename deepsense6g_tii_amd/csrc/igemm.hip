@@ -22,6 +22,8 @@
 #include "common.h"
 #include <vector>
 
+extern int g_ds6g_attn_percu;  // attention.hip: split-heuristic override (timing experiments)
+
 // LDS stages of the k loop (DMA runs STAGES-1 k-tiles ahead).  Measured on gfx950 (tools/bench_igemm.py): fwd / dgrad
 // gain 2-11 % from a third stage (more bytes in flight per CU outweigh 8 -> 6 resident workgroups), wgrad (128x64
 // tiles, 12 KB per stage) loses 1-3 %.
@@ -875,10 +877,11 @@ int ds6g_profile_end(int* variants, double* flops, float* ms, int cap) {
 }
 int ds6g_set_debug_flags(int flags) {
     g_dbg = flags & 0xbf;  // 0x80: force the general (FAST 0) walk
+    g_ds6g_attn_percu = (flags >> 20) & 0xf;  // attention: resident-workgroups-per-CU assumption of the split heuristic
     g_bf16_bk32 = (flags & 0x10000000) ? 0 : 1;
     g_f32_bk32 = (flags & 0x20000000) ? 1 : ((flags & 0x40000000) ? 0 : 2);   // fp32 32-column k-tiles: everywhere / never  // bf16 mode: 16-column k-tiles everywhere (A/B experiment)
     g_wgrad_tile = (flags & 0x40) ? 2 : 1;
-    if ((flags >> 8) & 0xfffff) g_min_blocks = (flags >> 8) & 0xfffff;
+    if ((flags >> 8) & 0xfff) g_min_blocks = (flags >> 8) & 0xfff;
     return 0;
 }
 
