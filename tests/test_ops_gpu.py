@@ -487,3 +487,36 @@ def test_pack_input_and_misc(dev):
     back = torch.empty(64 * 49, 3, device=dev)
     lib().pad_channels(wp.data_ptr(), back.data_ptr(), 64 * 49, 3, 4, 1, 0, st)
     close(back, w, 0, 0)
+
+
+def test_cabi_error_behaviour(dev):
+    """Bad arguments come back as a non-zero return code (raised as Ds6gError by the binding) without launching
+    anything and without poisoning later calls (the library clears sticky HIP errors on entry)."""
+    from deepsense6g_tii_amd._lib import Ds6gError, lib
+    ops = _ops()
+    L = lib()
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(8, 8, 8, 6, device=dev)      # C = 6: not a multiple of 4
+    w = torch.randn(16, 3, 3, 6, device=dev)
+    y = torch.empty(8, 8, 8, 16, device=dev)
+    with pytest.raises(Ds6gError):
+        L.conv2d_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), 8, 8, 8, 6, 16, 3, 3, 1, 1, st)
+    with pytest.raises(Ds6gError):               # null pointer
+        L.conv2d_fwd(0, w.data_ptr(), y.data_ptr(), 8, 8, 8, 8, 16, 3, 3, 1, 1, st)
+    q = torch.randn(64, 96, device=dev)          # head dim 24: unsupported
+    o = torch.empty_like(q)
+    lse = torch.empty(1, 4, 64, device=dev)
+    with pytest.raises(Ds6gError):
+        L.attention_fwd(q.data_ptr(), q.data_ptr(), q.data_ptr(), o.data_ptr(), lse.data_ptr(), 1, 64, 4, 24, 96, 96, 0.0,
+                        0, 0, 0, 0, st)
+    with pytest.raises(Ds6gError):               # dropout probability out of range
+        L.linear_fwd(q.data_ptr(), q.data_ptr(), 0, o.data_ptr(), 64, 96, 96, 0, 0, 1.5, 0, 0, st)
+    with pytest.raises(Ds6gError):               # GRU head width other than 64
+        L.gru_head_fwd(q.data_ptr(), q.data_ptr(), q.data_ptr(), q.data_ptr(), q.data_ptr(), q.data_ptr(), q.data_ptr(),
+                       o.data_ptr(), 0, 1, 5, 32, st)
+    # a correct call right after the failures still works
+    xg = torch.randn(2, 8, 8, 8, device=dev)
+    wg = torch.randn(16, 3, 3, 8, device=dev)
+    yg = ops.conv2d_fwd(xg, wg.data_ptr(), 16, 3, 3, 1, 1)
+    ref = torch.nn.functional.conv2d(xg.cpu().permute(0, 3, 1, 2), wg.cpu().permute(0, 3, 1, 2), None, 1, 1)
+    close(yg.cpu().permute(0, 3, 1, 2), ref, 1e-4, 1e-5)
