@@ -276,7 +276,9 @@ template <int C>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ add,
-                                                     float* __restrict__ dx, float* __restrict__ partial, int M) {
+                                                     float* __restrict__ dx, float* __restrict__ partial, int M,
+                                                     float* __restrict__ dx_drop, uint32_t thr, float dscale,
+                                                     uint64_t seed, uint64_t seed_off) {
     using R = LnRow<C>;
     __shared__ float red[4][2][C];
     const int lane = threadIdx.x & 63;
@@ -315,6 +317,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             dyv[e] = v;
         }
         R::store(dyv, dx + o, lane);
+        if (dx_drop) {  // the consumer of dx on the dropout branch (resid_drop of the block below) wants dropout(dx)
+#pragma unroll
+            for (int e = 0; e < R::NE; ++e)
+                dyv[e] = ds6g_keep(seed, seed_off + o + R::col(e, lane), thr) ? dyv[e] * dscale : 0.f;
+            R::store(dyv, dx_drop + o, lane);
+        }
     }
 #pragma unroll
     for (int e = 0; e < R::NE; ++e) {
@@ -490,9 +498,13 @@ size_t ds6g_layernorm_bwd_workspace_bytes(int M, int C) { return (size_t)cdiv(M,
 // dx = add? + LN'(dy); dgamma/dbeta (+)=
 int ds6g_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        const float* add, float* dx, float* dgamma, float* dbeta, int M, int C,
-                       int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream) {
+                       int accumulate_param_grads, float* dx_drop, float drop_p, uint64_t seed, uint64_t seed_off,
+                       void* ws, size_t ws_bytes, void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws);
+    DS6G_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
+    const uint32_t thr = ds6g_drop_threshold(drop_p);
+    const float dscale = 1.f / (1.f - drop_p);
     DS6G_CHECK_ARG(C % 64 == 0 && C <= 512);
     DS6G_CHECK_ARG(ws_bytes >= ds6g_layernorm_bwd_workspace_bytes(M, C));
     const int nblk = cdiv(M, LN_BWD_ROWS);
@@ -500,10 +512,10 @@ int ds6g_layernorm_bwd(const float* dy, const float* x, const float* mean, const
     dim3 grid(nblk), block(256);
     hipStream_t st = (hipStream_t)stream;
     switch (C / 64) {
-        case 1: hipLaunchKernelGGL((ln_bwd_kernel<64>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M); break;
-        case 2: hipLaunchKernelGGL((ln_bwd_kernel<128>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M); break;
-        case 4: hipLaunchKernelGGL((ln_bwd_kernel<256>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M); break;
-        case 8: hipLaunchKernelGGL((ln_bwd_kernel<512>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M); break;
+        case 1: hipLaunchKernelGGL((ln_bwd_kernel<64>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off); break;
+        case 2: hipLaunchKernelGGL((ln_bwd_kernel<128>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off); break;
+        case 4: hipLaunchKernelGGL((ln_bwd_kernel<256>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off); break;
+        case 8: hipLaunchKernelGGL((ln_bwd_kernel<512>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off); break;
         default: DS6G_CHECK_ARG(!"LayerNorm width must be 64/128/256/512");
     }
     DS6G_LAUNCH_CHECK();

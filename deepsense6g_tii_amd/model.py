@@ -781,24 +781,27 @@ class TransFuser(nn.Module):
                              accumulate=True)
         return dx
 
-    def _gpt_block_bwd(self, blk, ctx, dx2, B, T):
+    def _gpt_block_bwd(self, blk, ctx, dx2, B, T, dz2=None, next_drop=None):
+        """dx2: gradient of the block output; dz2: dropout(dx2) on this block's resid_drop mask if the producer of
+        dx2 already emitted it (fused into its LayerNorm backward); next_drop = (p, seed, off) of the block below:
+        the final LayerNorm backward then also emits dropout(dx).  Returns (dx, dropout(dx) or None)."""
         (x, h, m1, r1, q, k, v, y, lse, off_a, pa, off_p, pr, x1, h2, m2, r2, f1, off_m) = ctx
         C = x.shape[1]
         nh = self.config.n_head
         at = blk.attn
         fc1, fc2 = blk.mlp[0], blk.mlp[2]
         # x2 = x1 + drop(fc2(f1))
-        dz2 = ops.dropout(dx2, pr, self._seed, off_m) if pr > 0 else dx2
+        if dz2 is None:
+            dz2 = ops.dropout(dx2, pr, self._seed, off_m) if pr > 0 else dx2
         self._lin_param_grads(fc2, f1, dz2)
         df1 = ops.linear_dgrad(dz2, self._w(fc2.weight), fc1.out_features, relu_mask_src=f1)
         self._lin_param_grads(fc1, h2, df1)
         dh2 = ops.linear_dgrad(df1, self._w(fc1.weight), C)
         g2w, a2 = self._g(blk.ln2.weight)
         g2b, _ = self._g(blk.ln2.bias)
-        dx1 = ops.layernorm_bwd(dh2, x1, m2, r2, self._w(blk.ln2.weight), g2w, g2b, self._ws, add=dx2,
-                                accumulate=bool(a2))
-        # x1 = x + drop(proj(y))
-        dz1 = ops.dropout(dx1, pr, self._seed, off_p) if pr > 0 else dx1
+        # x1 = x + drop(proj(y)): the LayerNorm backward emits dx1 and dropout(dx1) together
+        dx1, dz1 = ops.layernorm_bwd(dh2, x1, m2, r2, self._w(blk.ln2.weight), g2w, g2b, self._ws, add=dx2,
+                                     accumulate=bool(a2), drop=(pr, self._seed, off_p))
         self._lin_param_grads(at.proj, y, dz1)
         dy = ops.linear_dgrad(dz1, self._w(at.proj.weight), C)
         fw = self._qkv_fused(at) if self.fuse_qkv else None
@@ -819,9 +822,12 @@ class TransFuser(nn.Module):
             ops.linear_dgrad(dv, self._w(at.value.weight), C, out=dh, accumulate=True)
         g1w, a1 = self._g(blk.ln1.weight)
         g1b, _ = self._g(blk.ln1.bias)
+        if next_drop is not None:
+            return ops.layernorm_bwd(dh, x, m1, r1, self._w(blk.ln1.weight), g1w, g1b, self._ws, add=dx1,
+                                     accumulate=bool(a1), drop=next_drop)
         dx = ops.layernorm_bwd(dh, x, m1, r1, self._w(blk.ln1.weight), g1w, g1b, self._ws, add=dx1,
                                accumulate=bool(a1))
-        return dx
+        return dx, None
 
     def _stage_bwd(self, ctx, dfeats_out, dgps_tok, B):
         """dfeats_out: grads of the 3 post-fusion maps; dgps_tok: (tensor, bcast) grad of the GPS rows of
@@ -840,9 +846,12 @@ class TransFuser(nn.Module):
         L.gps_rows(gsrc.data_ptr(), dxo.data_ptr(), B, C, T, 1, 0, int(bcast), st)
         gfw, af = self._g(gpt.ln_f.weight)
         gfb, _ = self._g(gpt.ln_f.bias)
-        dx = ops.layernorm_bwd(dxo, x_last, mf, rf, self._w(gpt.ln_f.weight), gfw, gfb, self._ws, accumulate=bool(af))
-        for blk, bc in zip(reversed(list(gpt.blocks)), reversed(blk_ctx)):
-            dx = self._gpt_block_bwd(blk, bc, dx, B, T)
+        rev = list(zip(reversed(list(gpt.blocks)), reversed(blk_ctx)))
+        drops = [(bc[12], self._seed, bc[18]) for _, bc in rev]  # (resid_pdrop, seed, fc2-branch mask offset) per block
+        dx, dz = ops.layernorm_bwd(dxo, x_last, mf, rf, self._w(gpt.ln_f.weight), gfw, gfb, self._ws,
+                                   accumulate=bool(af), drop=drops[0])
+        for i, (blk, bc) in enumerate(rev):
+            dx, dz = self._gpt_block_bwd(blk, bc, dx, B, T, dz2=dz, next_drop=drops[i + 1] if i + 1 < len(rev) else None)
         self._wg_join()
         dpre = ops.dropout(dx, pe, self._seed, off_e) if pe > 0 else dx
         gpos, apos = self._g(gpt.pos_emb)

@@ -184,16 +184,19 @@ def layernorm_fwd(x, gamma_ptr, beta_ptr, eps=1e-5):
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma_ptr, dgamma_ptr, dbeta_ptr, ws: Workspace, add=None, accumulate=False,
-                  out=None):
+                  out=None, drop=None):
+    """-> dx, or (dx, dropout(dx)) when drop = (p, seed, seed_off) with p > 0 (fused second output)"""
     M, C = x.shape
     _chk(dy, M, C)
     _chk(x)
     dx = out if out is not None else torch.empty_like(x)
     if add is not None:
         _chk(add, M, C)
+    dxd = torch.empty_like(x) if (drop is not None and drop[0] > 0) else None
+    p, seed, off = drop if dxd is not None else (0.0, 0, 0)
     lib().layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), gamma_ptr, _p(add), _p(dx), dgamma_ptr, dbeta_ptr, M, C,
-                        int(accumulate), ws.ptr, ws.nbytes, _stream())
-    return dx
+                        int(accumulate), _p(dxd), float(p), seed, off, ws.ptr, ws.nbytes, _stream())
+    return dx if drop is None else (dx, dxd if dxd is not None else dx)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -88,9 +88,12 @@ int ds6g_bn_bwd(const float* dy, const float* y_mask, const float* x, const floa
 int ds6g_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                        int M, int C, float eps, void* stream);
 size_t ds6g_layernorm_bwd_workspace_bytes(int M, int C);
+/* dx = add? + LN'(dy); dgamma / dbeta (+)=.  dx_drop (nullable): also writes dropout(dx; drop_p, seed, seed_off), the
+ * gradient the resid_drop branch of the block below consumes (model2_seq.py:109,126), saving a separate pass. */
 int ds6g_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        const float* add, float* dx, float* dgamma, float* dbeta, int M, int C,
-                       int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream);
+                       int accumulate_param_grads, float* dx_drop, float drop_p, uint64_t seed, uint64_t seed_off,
+                       void* ws, size_t ws_bytes, void* stream);
 /* bias gradients: out[c] (+)= sum_r x[r][c] */
 size_t ds6g_colsum_workspace_bytes(long M, int C);
 int ds6g_colsum(const float* x, long M, int C, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream);

@@ -217,6 +217,14 @@ def test_layernorm(dev, M, C):
     close(dx, x.grad + add, 1e-5, 1e-5)
     close(dgam, gamma.grad, 1e-4, 1e-4)
     close(dbet, beta.grad, 1e-4, 1e-4)
+    # fused second output: dropout(dx) with the mask of the standalone dropout kernel (same counter hash)
+    dx2, dxd = ops.layernorm_bwd(dy.cuda(), xg, mean, rstd, gg.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), ws,
+                                 add=add.cuda(), drop=(0.1, 1234, 4096))
+    assert torch.equal(dx2, dx)
+    assert torch.equal(dxd, ops.dropout(dx, 0.1, 1234, 4096))
+    dx3, same = ops.layernorm_bwd(dy.cuda(), xg, mean, rstd, gg.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), ws,
+                                  add=add.cuda(), drop=(0.0, 0, 0))
+    assert same is dx3 and torch.equal(dx3, dx)
 
 
 def _attn_ref(q, k, v, B, T, nh):
