@@ -205,13 +205,14 @@ def main():
         return v["hbm_bytes_per_launch"] if v else None
 
     def vname(v, short=False):
-        # variant code (include/ds6g.h): 1000 * epilogue + 100 * uniform-walk + 10 * mode + tile  ->  the template
-        # instantiation exactly as rocprofv3 names it: igemm_kernel<mode, BM, BN, epilogue, 16, bf16, walk>
-        epi, walk, mode, tile = v // 1000, v % 1000 // 100, v % 100 // 10, v % 10
+        # variant code (include/ds6g.h): 10000 * wide + 1000 * epilogue + 100 * uniform-walk + 10 * mode + tile  ->  the template
+        # instantiation exactly as rocprofv3 names it: igemm_kernel<mode, BM, BN, epilogue, BK, bf16, walk>
+        wide, epi, walk, mode, tile = v // 10000, v % 10000 // 1000, v % 1000 // 100, v % 100 // 10, v % 10
         bm, bn = VARIANT_NAMES[tile].split("x")
         if short:
-            return f"{MODE_NAMES[mode]}/{bm}x{bn}" + ("/epi" if epi else "") + ("" if walk else "/general-walk")
-        return f"igemm_kernel<{mode}, {bm}, {bn}, {epi}, 16, {1 if args.dtype == 'bf16' else 0}, {walk}>"
+            return (f"{MODE_NAMES[mode]}/{bm}x{bn}" + ("/k32" if wide else "") + ("/epi" if epi else "") +
+                    ("" if walk else "/general-walk"))
+        return f"igemm_kernel<{mode}, {bm}, {bn}, {epi}, {32 if wide else 16}, {1 if args.dtype == 'bf16' else 0}, {walk}>"
 
     if agg:
         dom = max(agg, key=lambda v: agg[v][2])

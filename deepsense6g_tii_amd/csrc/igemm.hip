@@ -734,31 +734,30 @@ int launch_igemm(IgemmParams& p, int splits, int tile, hipStream_t st) {
     // BK = 32 was measured (tools/bench_igemm.py): within +-5 % on fwd/dgrad, 10-30 % slower on wgrad -> BK = 16
     const bool fast = fast_walk_ok<MODE>(p) && !(g_dbg & 0x80);
     const bool epi = MODE != MODE_WGRAD && full;
+    // 32-column k-tiles: bf16 mode - one MFMA per 16 columns makes the k-tile bookkeeping (DMA issue, barrier) the
+    // bottleneck, so fwd / dgrad use two MFMAs per barrier wherever the uniform walk allows it (wgrad was measured with
+    // 32-pixel k-tiles too: no gain, its k-major fragments are LDS-read bound); fp32 - pays on the small-spatial conv
+    // layers (16x16, 8x8: few workgroups per CU, +4-15 %), not on the large ones, the GPT linears or any wgrad
+    // (measured, tools/bench_igemm.py)
+    const bool can32 = MODE != MODE_WGRAD && fast && fast_walk_ok<MODE>(p, 32);
+    const bool bk32 = can32 && (g_ds6g_bf16 ? g_bf16_bk32 != 0
+                                            : (g_f32_bk32 == 1 || (g_f32_bk32 == 2 && !p.is_linear && p.R * p.S > 1 &&
+                                                                   (long)cdiv(p.Mg, 64) * cdiv(p.Ng, 64) <= 1024)));
+    const int variant = 10000 * (int)bk32 + 1000 * (int)epi + 100 * (int)fast + 10 * MODE + tile;
     ProfRec* rec = nullptr;
     if (g_prof && g_prof->size() < g_prof_cap) {
         g_prof->push_back(ProfRec{});
         rec = &g_prof->back();
-        rec->variant = 1000 * (int)epi + 100 * (int)fast + 10 * MODE + tile;
+        rec->variant = variant;
         rec->flops = p.prof_flops > 0 ? p.prof_flops : 2.0 * p.Mg * p.Ng * p.Kg;
         (void)hipEventCreate(&rec->e0);
         (void)hipEventCreate(&rec->e1);
         (void)hipEventRecord(rec->e0, st);
     }
-    // bf16 mode: one MFMA per 16 columns makes the k-tile bookkeeping (DMA issue, barrier) the bottleneck - fwd / dgrad
-    // use 32-column k-tiles (two MFMAs per barrier) wherever the uniform walk allows it
-    // (wgrad was measured with 32-pixel k-tiles too: no gain, its k-major fragments are LDS-read bound)
-    const bool bk32 = g_ds6g_bf16 && g_bf16_bk32 && MODE != MODE_WGRAD && fast && fast_walk_ok<MODE>(p, 32);
     if (bk32) {
         if constexpr (MODE != MODE_WGRAD) {
-            if (epi) launch_tile<MODE, 1, 32, 1, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 32, 1, 1>(p, splits, tile, st);
-        }
-    } else if (!g_ds6g_bf16 && MODE != MODE_WGRAD && fast && fast_walk_ok<MODE>(p, 32) &&
-               (g_f32_bk32 == 1 || (g_f32_bk32 == 2 && !p.is_linear && p.R * p.S > 1 &&
-                                    (long)cdiv(p.Mg, 64) * cdiv(p.Ng, 64) <= 1024))) {
-        // fp32: 32-column k-tiles (two LDS stages) pay on the small-spatial conv layers (16x16, 8x8: few workgroups
-        // per CU, +4-15 %), not on the large ones, the GPT linears or any wgrad (measured, tools/bench_igemm.py)
-        if constexpr (MODE != MODE_WGRAD) {
-            if (epi) launch_tile<MODE, 1, 32, 0, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 32, 0, 1>(p, splits, tile, st);
+            if (g_ds6g_bf16) { if (epi) launch_tile<MODE, 1, 32, 1, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 32, 1, 1>(p, splits, tile, st); }
+            else             { if (epi) launch_tile<MODE, 1, 32, 0, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 32, 0, 1>(p, splits, tile, st); }
         }
     } else if (g_ds6g_bf16) {
         if (fast) { if (epi) launch_tile<MODE, 1, 16, 1, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 1, 1>(p, splits, tile, st); }
@@ -768,7 +767,7 @@ int launch_igemm(IgemmParams& p, int splits, int tile, hipStream_t st) {
         else      { if (epi) launch_tile<MODE, 1, 16, 0, 0>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 0, 0>(p, splits, tile, st); }
     }
     if (rec) (void)hipEventRecord(rec->e1, st);
-    g_last_variant = 1000 * (int)epi + 100 * (int)fast + 10 * MODE + tile;
+    g_last_variant = variant;
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }
@@ -879,7 +878,7 @@ int ds6g_set_debug_flags(int flags) {
     g_dbg = flags & 0xbf;  // 0x80: force the general (FAST 0) walk
     g_ds6g_attn_percu = (flags >> 20) & 0xf;  // attention: resident-workgroups-per-CU assumption of the split heuristic
     g_bf16_bk32 = (flags & 0x10000000) ? 0 : 1;
-    g_f32_bk32 = (flags & 0x20000000) ? 1 : ((flags & 0x40000000) ? 0 : 2);   // fp32 32-column k-tiles: everywhere / never  // bf16 mode: 16-column k-tiles everywhere (A/B experiment)
+    g_f32_bk32 = (flags & 0x20000000) ? 1 : ((flags & 0x40000000) ? 0 : 2);   // fp32 32-column k-tiles: everywhere / never
     g_wgrad_tile = (flags & 0x40) ? 2 : 1;
     if ((flags >> 8) & 0xfff) g_min_blocks = (flags >> 8) & 0xfff;
     return 0;

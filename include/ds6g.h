@@ -23,10 +23,11 @@ extern "C" {
 #endif
 
 int ds6g_version(void);
-/* which implicit-GEMM instantiation the last conv/linear call launched: 1000*epilogue + 100*walk + 10*mode + tile
- * (epilogue 1 = fused bias/ReLU/dropout/residual epilogue, 0 = plain store; walk 1 = wave-uniform k walk, 0 = general
- * walk; mode 0 fwd, 1 dgrad, 2 wgrad; tile 0 128x128, 1 128x64, 2 64x64), i.e. the template arguments of
- * igemm_kernel<mode, BM, BN, epilogue, 16, bf16, walk> as rocprofv3 prints them.  Bench instrumentation only. */
+/* which implicit-GEMM instantiation the last conv/linear call launched: 10000*wide + 1000*epilogue + 100*walk +
+ * 10*mode + tile (wide 1 = 32-column k-tiles, 0 = 16; epilogue 1 = fused bias/ReLU/dropout/residual epilogue, 0 = plain
+ * store; walk 1 = wave-uniform k walk, 0 = general walk; mode 0 fwd, 1 dgrad, 2 wgrad; tile 0 128x128, 1 128x64,
+ * 2 64x64), i.e. the template arguments of igemm_kernel<mode, BM, BN, epilogue, BK, bf16, walk> as rocprofv3 prints
+ * them.  Bench instrumentation only. */
 int ds6g_last_igemm_variant(void);
 /* bench instrumentation: between profile_begin and profile_end every implicit-GEMM KERNEL launch (not the split-K
  * reduction that may follow it) is bracketed by HIP events on its launch stream.  profile_end synchronises and returns
