@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
 // PART 0 = both (4 products per tile); 1 = dV only (S, dV); 2 = dK only (S, dP, dK).  At HD = 128 the fused form
 // needs > 512 registers (K, V fragments + two accumulator sets), so it runs as PART 1 + PART 2.
 template <int HD, int PART, int BF>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, (HD <= 32 ? 3 : (HD <= 64 ? 2 : 1))) void attn_bwd_dkv_kernel(const AttnParams p) {
     constexpr bool DO_DV = PART != 2, DO_DK = PART != 1;
     ATTN_COMMON();
     __shared__ float lse_s[2][32];
@@ -689,7 +689,7 @@ int ds6g_attention_bwd(const float* q, const float* k, const float* v, const flo
     // ---- dK, dV (split over queries)
     {
         const size_t max_by_ws = ws ? ws_bytes / (2 * slab * sizeof(float)) : 1;
-        int splits = pick_splits((long)blocks128 * nh * B, ntiles, hd >= 64 ? 1 : 2, (int)(max_by_ws < 8 ? max_by_ws : 8));
+        int splits = pick_splits((long)blocks128 * nh * B, ntiles, hd >= 128 ? 1 : (hd >= 64 ? 2 : 3), (int)(max_by_ws < 8 ? max_by_ws : 8));
         p.tiles_per_split = cdiv(ntiles, splits);
         splits = cdiv(ntiles, p.tiles_per_split);
         p.splits = splits;
