@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
 // PART 0 = both (4 products per tile); 1 = dV only (S, dV); 2 = dK only (S, dP, dK).  At HD = 128 the fused form
 // needs > 512 registers (K, V fragments + two accumulator sets), so it runs as PART 1 + PART 2.
 template <int HD, int PART, int BF>
-__global__ __launch_bounds__(256, (HD <= 32 ? 3 : (HD <= 64 ? 2 : 1))) void attn_bwd_dkv_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, (HD <= 32 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2 : 1)))) void attn_bwd_dkv_kernel(const AttnParams p) {
     constexpr bool DO_DV = PART != 2, DO_DK = PART != 1;
     ATTN_COMMON();
     __shared__ float lse_s[2][32];
