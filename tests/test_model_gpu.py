@@ -317,3 +317,20 @@ def test_eval_bn_folding_matches_unfolded(dev):
     ref = fr.transfuser_forward({k: v.cpu() for k, v in model.state_dict().items()}, imgs, lids, rads, gps, rcfg,
                                 fr.Ctx(training=False))
     assert rel(a, ref) < TOL
+
+
+def test_captured_inference_graph_matches_eager(dev):
+    """capture_inference(): the eval forward replayed from one HIP graph equals the eager forward bit for bit, follows
+    new inputs (static input buffers) and new weights (parameters are read at replay time)."""
+    from oracle import fusion_ref as fr
+    kw = dict(n_layer=1, embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
+    model, rcfg, sd = _build(dev, kw, seed=41)
+    model.eval()
+    a = fr.make_inputs(rcfg, 1, seed=50)[:4]
+    b = fr.make_inputs(rcfg, 1, seed=51)[:4]
+    run = model.capture_inference(*a)
+    with torch.no_grad():
+        assert torch.equal(run(*a), model(*a))
+        assert torch.equal(run(*b), model(*b))
+        model.join[4].bias.data.add_(1.0)          # in-place weight change is seen by the next replay
+        assert torch.equal(run(*b), model(*b))
