@@ -14,6 +14,15 @@ constexpr int BN_ROWS_PER_THREAD = 16;
 constexpr int FIN_COLS = 8;
 constexpr int FIN_GROUPS = 32;
 
+// BN output before the activation, ONE spelling shared by the forward (bn_apply) and by the backward kernels that
+// re-derive the ReLU mask from it instead of reading the activation tensor (identical rounding -> identical mask)
+__device__ __forceinline__ f32x4 bn_affine(const f32x4 x, const f32x4 mu, const f32x4 is, const f32x4 g, const f32x4 b) {
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = fmaf((x[j] - mu[j]) * is[j], g[j], b[j]);
+    return r;
+}
+
 // partial[blk][0][c] = sum_rows a(r,c), partial[blk][1][c] = sum_rows b(r,c) in fp64.
 // MODE 0: a = x, b = x*x.   MODE 1: a = dyeff, b = dyeff * xhat  (BN backward)
 template <int MODE>
@@ -21,7 +30,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
                                                         const float* __restrict__ y_mask,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, long M, int C,
-                                                        int rows_per_block, double* __restrict__ partial) {
+                                                        int rows_per_block, double* __restrict__ partial,
+                                                        const float* __restrict__ mg, const float* __restrict__ mb) {
     extern __shared__ __attribute__((aligned(16))) double red[];  // [rowlanes][2][C]
     const int cg = C >> 2;
     const int colg = threadIdx.x % cg;
@@ -31,9 +41,14 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     const long r1 = min(M, r0 + rows_per_block);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
+    f32x4 gam = {1.f, 1.f, 1.f, 1.f}, bet = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 1) {
         mu = *reinterpret_cast<const f32x4*>(mean + colg * 4);
         is = *reinterpret_cast<const f32x4*>(invstd + colg * 4);
+        if (mg) {  // ReLU mask recomputed from x (no residual on this BN): sign of gamma * xhat + beta
+            gam = *reinterpret_cast<const f32x4*>(mg + colg * 4);
+            bet = *reinterpret_cast<const f32x4*>(mb + colg * 4);
+        }
     }
     for (long r = r0 + rowlane; r < r1; r += rowlanes) {
         const size_t o = (size_t)r * C + colg * 4;
@@ -43,8 +58,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
             s2 += xv * xv;
         } else {
             f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
-            if (y_mask) {
-                const f32x4 yv = *reinterpret_cast<const f32x4*>(y_mask + o);
+            if (y_mask || mg) {
+                const f32x4 yv = mg ? bn_affine(xv, mu, is, gam, bet) : *reinterpret_cast<const f32x4*>(y_mask + o);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
             }
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c4);
         const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c4);
         f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
-        v = (v - mu) * is * g + b;
+        v = bn_affine(v, mu, is, g, b);
         if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
         if (relu) {
 #pragma unroll
@@ -175,7 +190,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, float* __restrict__ dx,
-                                                           float* __restrict__ dres, long total4, int C) {
+                                                           float* __restrict__ dres, long total4, int C,
+                                                           const float* __restrict__ mg, const float* __restrict__ mb) {
     const int cg = C >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % cg) * 4;
@@ -185,12 +201,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const f32x4 b = *reinterpret_cast<const f32x4*>(coef + C + c4);
         const f32x4 cc = *reinterpret_cast<const f32x4*>(coef + 2 * C + c4);
         f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
-        if (y_mask) {
-            const f32x4 yv = *reinterpret_cast<const f32x4*>(y_mask + i * 4);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
+        if (y_mask || mg) {
+            const f32x4 yv = mg ? bn_affine(xv, mu, is, *reinterpret_cast<const f32x4*>(mg + c4),
+                                            *reinterpret_cast<const f32x4*>(mb + c4))
+                                : *reinterpret_cast<const f32x4*>(y_mask + i * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
         }
-        const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + i * 4) - mu) * is;
+        const f32x4 xh = (xv - mu) * is;
         if (dres) *reinterpret_cast<f32x4*>(dres + i * 4) = g;
         *reinterpret_cast<f32x4*>(dx + i * 4) = a * (g - b - xh * cc);
     }
@@ -418,7 +437,7 @@ int ds6g_bn_stats(const float* x, long M, int C, float eps, float momentum, floa
     double* partial = (double*)ws;
     const size_t lds = (size_t)(256 / (C / 4)) * 2 * C * sizeof(double);
     hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, x, nullptr, nullptr,
-                       nullptr, nullptr, M, C, rpb, partial);
+                       nullptr, nullptr, M, C, rpb, partial, nullptr, nullptr);
     DS6G_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk,
                        M, C, eps, momentum, mean, invstd, running_mean, running_var);
@@ -449,11 +468,15 @@ int ds6g_bn_apply(const float* x, const float* mean, const float* invstd, const 
 }
 
 // dyeff = dy * (y_mask > 0) (y_mask nullable); dx = gamma*invstd*(dyeff - mean(dyeff) - xhat*mean(dyeff*xhat));
-// dgamma/dbeta (+)=; dres (nullable) receives dyeff (gradient of the residual branch)
+// dgamma/dbeta (+)=; dres (nullable) receives dyeff (gradient of the residual branch).
+// relu_beta (nullable, with y_mask NULL): the BN was followed by ReLU with NO residual added in between - the mask is
+// re-derived as (gamma * xhat + relu_beta > 0) from x, which the kernels read anyway, instead of reading the activation
 int ds6g_bn_bwd(const float* dy, const float* y_mask, const float* x, const float* mean, const float* invstd,
-                const float* gamma, float* dx, float* dgamma, float* dbeta, float* dres, long M, int C,
-                int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream) {
+                const float* gamma, const float* relu_beta, float* dx, float* dgamma, float* dbeta, float* dres, long M,
+                int C, int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream) {
     DS6G_ENTER();
+    DS6G_CHECK_ARG(!(y_mask && relu_beta));
+    const float* mg = relu_beta ? gamma : nullptr;
     int rpb, nblk;
     DS6G_CHECK_ARG(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && ws);
     DS6G_CHECK_ARG(bn_geometry(M, C, &rpb, &nblk) == DS6G_OK);
@@ -462,7 +485,7 @@ int ds6g_bn_bwd(const float* dy, const float* y_mask, const float* x, const floa
     float* coef = (float*)((char*)ws + (size_t)nblk * 2 * C * sizeof(double));
     const size_t lds = (size_t)(256 / (C / 4)) * 2 * C * sizeof(double);
     hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, x, dy, y_mask, mean,
-                       invstd, M, C, rpb, partial);
+                       invstd, M, C, rpb, partial, mg, relu_beta);
     DS6G_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk, M,
                        C, gamma, invstd, dgamma, dbeta, coef, accumulate_param_grads);
@@ -470,7 +493,7 @@ int ds6g_bn_bwd(const float* dy, const float* y_mask, const float* x, const floa
     const long total4 = M * C / 4;
     const int grid = (int)min((long)8192, (total4 + 255) / 256);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, y_mask, x, mean,
-                       invstd, coef, dx, dres, total4, C);
+                       invstd, coef, dx, dres, total4, C, mg, relu_beta);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }

@@ -777,9 +777,15 @@ class TransFuser(nn.Module):
             self._wg_used = {}
         self._wg_keep = []
 
-    def _bn_bwd(self, bn, dy, y_mask, x, stats, want_dres=False):
+    def _bn_bwd(self, bn, dy, y_mask, x, stats, want_dres=False, relu_no_residual=False):
+        """relu_no_residual: y_mask is relu(bn(x)) itself (bn1 of a block / of the stem) - its sign is recomputed from
+        x inside the kernels instead of reading the activation tensor twice"""
         gw, aw = self._g(bn.weight)
         gb, ab = self._g(bn.bias)
+        if relu_no_residual:
+            dx, dres = ops.bn_bwd(dy, None, x, stats[0], stats[1], self._w(bn.weight), gw, gb, self._ws,
+                                  want_dres=want_dres, accumulate=bool(aw), relu_beta_ptr=self._w(bn.bias))
+            return dx, dres
         dx, dres = ops.bn_bwd(dy, y_mask, x, stats[0], stats[1], self._w(bn.weight), gw, gb, self._ws,
                               want_dres=want_dres, accumulate=bool(aw))
         return dx, dres
@@ -797,7 +803,7 @@ class TransFuser(nn.Module):
         dc2, dres = self._bn_bwd(blk.bn2, dout, out, c2, s2, want_dres=True)
         self._wgrad_conv(blk.conv2, a1, dc2, 3, 1, 1)
         da1 = ops.conv2d_dgrad(dc2, self._w(blk.conv2.weight), tuple(a1.shape), 3, 3, 1, 1)
-        dc1, _ = self._bn_bwd(blk.bn1, da1, a1, c1, s1)
+        dc1, _ = self._bn_bwd(blk.bn1, da1, a1, c1, s1, relu_no_residual=True)
         self._wgrad_conv(blk.conv1, x, dc1, 3, blk.stride, 1)
         if blk.downsample is not None:
             dcd, _ = self._bn_bwd(blk.downsample[1], dres, None, cd, sd)
@@ -914,7 +920,7 @@ class TransFuser(nn.Module):
         N, H1, W1, _ = a1.shape
         da1 = torch.empty_like(a1)
         L.maxpool3x3s2_bwd(dpool.data_ptr(), idx.data_ptr(), da1.data_ptr(), N, H1, W1, 64, st)
-        dc1, _ = self._bn_bwd(trunk.bn1, da1, a1, c1, st1)
+        dc1, _ = self._bn_bwd(trunk.bn1, da1, a1, c1, st1, relu_no_residual=True)
         dwpad = torch.empty((64, 7, 7, 4), dtype=F32, device=self.device)
         gw, aw = self._g(trunk.conv1.weight)
 

@@ -161,15 +161,17 @@ def bn_apply(x, mean, invstd, gamma_ptr, beta_ptr, relu, residual=None, out=None
 
 
 def bn_bwd(dy, y_mask, x, mean, invstd, gamma_ptr, dgamma_ptr, dbeta_ptr, ws: Workspace, want_dres=False,
-           accumulate=False, dx_out=None):
+           accumulate=False, dx_out=None, relu_beta_ptr=0):
+    """y_mask: activation tensor whose sign gives the ReLU mask, or None; relu_beta_ptr (with y_mask None): BN -> ReLU
+    without a residual in between - the mask is recomputed from x inside the kernels."""
     _chk(dy, *x.shape)
     _chk(x)
     C = x.shape[-1]
     M = x.numel() // C
     dx = dx_out if dx_out is not None else torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
-    lib().bn_bwd(_p(dy), _p(y_mask), _p(x), _p(mean), _p(invstd), gamma_ptr, _p(dx), dgamma_ptr, dbeta_ptr, _p(dres),
-                 M, C, int(accumulate), ws.ptr, ws.nbytes, _stream())
+    lib().bn_bwd(_p(dy), _p(y_mask), _p(x), _p(mean), _p(invstd), gamma_ptr, relu_beta_ptr, _p(dx), dgamma_ptr, dbeta_ptr,
+                 _p(dres), M, C, int(accumulate), ws.ptr, ws.nbytes, _stream())
     return dx, dres
 
 

@@ -82,9 +82,12 @@ int ds6g_bn_eval_prepare(const float* running_mean, const float* running_var, in
                          float* invstd, void* stream);
 int ds6g_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                   const float* residual, float* y, long M, int C, int relu, void* stream);
+/* relu_beta (nullable, y_mask then NULL): the BN fed a ReLU with no residual in between (bn1 of a BasicBlock, stem
+ * bn1): the ReLU mask is re-derived from x as (gamma * xhat + relu_beta > 0) with the forward's own arithmetic instead of
+ * reading the activation tensor - one tensor read less in each of the two backward passes. */
 int ds6g_bn_bwd(const float* dy, const float* y_mask, const float* x, const float* mean, const float* invstd,
-                const float* gamma, float* dx, float* dgamma, float* dbeta, float* dres, long M, int C,
-                int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream);
+                const float* gamma, const float* relu_beta, float* dx, float* dgamma, float* dbeta, float* dres, long M,
+                int C, int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream);
 /* nn.LayerNorm(C), eps 1e-5: model2_seq.py:118-119,131-132,199,274.  C in {64,128,256,512}. */
 int ds6g_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                        int M, int C, float eps, void* stream);

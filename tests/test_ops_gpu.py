@@ -189,6 +189,16 @@ def test_batchnorm(dev, M, C):
     close(dres, res.grad, 1e-5, 1e-6)
     close(dgam, gamma.grad, 1e-4, 1e-4)
     close(dbet, beta.grad, 1e-4, 1e-4)
+    # BN -> ReLU without a residual: the backward re-derives the mask from x; it must equal the backward that reads
+    # the activation relu(bn(x)) produced by bn_apply, bit for bit (same mask, same arithmetic)
+    act = ops.bn_apply(xg, mean, invstd, gg.data_ptr(), bg.data_ptr(), True)
+    dyg = dout.reshape(C, M).t().contiguous().cuda()
+    d1, g1, b1 = torch.empty_like(xg), torch.empty(C, device=dev), torch.empty(C, device=dev)
+    d2, g2, b2 = torch.empty_like(xg), torch.empty(C, device=dev), torch.empty(C, device=dev)
+    ops.bn_bwd(dyg, act, xg, mean, invstd, gg.data_ptr(), g1.data_ptr(), b1.data_ptr(), ws, dx_out=d1)
+    ops.bn_bwd(dyg, None, xg, mean, invstd, gg.data_ptr(), g2.data_ptr(), b2.data_ptr(), ws, dx_out=d2,
+               relu_beta_ptr=bg.data_ptr())
+    assert torch.equal(d1, d2) and torch.equal(g1, g2) and torch.equal(b1, b2)
     # eval-mode prepare
     ops.bn_eval_prepare(rmg.data_ptr(), rvg.data_ptr(), C, mean, invstd)
     ye = ops.bn_apply(xg, mean, invstd, gg.data_ptr(), bg.data_ptr(), False)
