@@ -1,0 +1,283 @@
+// Winograd F(2x2, 3x3) convolution for the 3x3 / stride 1 / pad 1 layers of the ResNet trunks
+// (torchvision BasicBlock conv1 / conv2 at call sites /root/reference/model2_seq.py:510-512,528-530,546-548,565-567):
+// 16 small GEMMs over 4x4-transformed input tiles instead of 9 taps - 2.25x fewer matrix-core FLOPs, which is the
+// lever that is left once the direct implicit GEMM sits at the chip's power-limited fp32 MFMA rate.
+//
+//   V_p[tile][c] = (B^T d B)_p        input transform  (p = 0..15, d = the 4x4 input patch of a 2x2 output tile)
+//   M_p[tile][k] = sum_c V_p[tile][c] * U_p[k][c]      16 GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32 products)
+//   y            = A^T M A            output transform
+// with U_p = (G g G^T)_p precomputed per call by winograd_weights_kernel (weights change every optimizer step).
+//
+// One workgroup = 32 tiles (BTH x BTW tile rows/columns) x 32 output channels; wave w owns transform positions
+// 4w..4w+3.  Per 16-channel chunk: every thread loads its (tile, channel-pair) 4x4 patch straight from global memory
+// (buffer loads, out-of-image pixels read 0), transforms it in registers and writes the 16 V values into the LDS image
+// the MFMA A-fragments are read from (same [row][16] + XOR-swizzle image as igemm.hip); the B operand (U) goes
+// global -> registers directly in fragment layout (each wave needs only its own 4 positions: nothing to share).
+// The next chunk's patch and U fragments are prefetched into registers while the MFMAs of the current chunk run.
+#include "common.h"
+
+namespace {
+
+constexpr int WG_TILES = 32;   // tiles per workgroup (MFMA rows)
+constexpr int WG_KB = 32;      // output channels per workgroup (MFMA columns)
+constexpr int WG_CH = 16;      // channels per chunk
+
+struct WinoParams {
+    const float* x;      // [N][H][W][C]
+    const float* u;      // [16][K][C]
+    float* y;            // [N][H][W][K]
+    int N, H, W, C, K;
+    int TH, TW;          // tiles per image column / row (H/2, W/2)
+    int BTH, BTW;        // tile rows / columns per workgroup (BTH * BTW = 32)
+    int rows_total;      // N * TH  (tile rows over the whole batch)
+    int col_blocks;      // TW / BTW
+    unsigned x_bytes, u_bytes;
+    int accumulate;      // y += result (data gradient summed onto the gradient of the residual branch)
+};
+
+// U[p][k][c] = (G g G^T)[p], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].  transpose_flip: build the dgrad filter
+// instead - input/output channels swapped and taps rotated by 180 degrees: g'[c][r][s][k] = g[k][2-r][2-s][c].
+__global__ __launch_bounds__(256) void winograd_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int K,
+                                                               int C, int transpose_flip) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Ko = transpose_flip ? C : K, Co = transpose_flip ? K : C;  // output-side (rows of U) / reduction side
+    if (i >= (long)Ko * Co) return;
+    const int ko = (int)(i / Co), co = (int)(i - (long)ko * Co);
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            g[r][s] = transpose_flip ? w[(((long)co * 3 + (2 - r)) * 3 + (2 - s)) * C + ko]
+                                     : w[(((long)ko * 3 + r) * 3 + s) * C + co];
+    float t[4][3];  // G g
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        t[0][s] = g[0][s];
+        t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+        t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+        t[3][s] = g[2][s];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float o0 = t[r][0];
+        const float o1 = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
+        const float o2 = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
+        const float o3 = t[r][2];
+        const size_t base = ((size_t)(r * 4) * Ko + ko) * Co + co;
+        u[base] = o0;
+        u[base + (size_t)Ko * Co] = o1;
+        u[base + 2 * (size_t)Ko * Co] = o2;
+        u[base + 3 * (size_t)Ko * Co] = o3;
+    }
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256, 2) void winograd_fwd_kernel(const WinoParams p) {
+    // V image: [16 positions][32 tiles][16 ch] (2 KiB per position); reused as M [16][32 tiles][32 k] at the end
+    __shared__ __attribute__((aligned(16))) float lds[16 * WG_TILES * WG_KB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, khalf = lane >> 5;
+    // workgroup -> (tile-row block, tile-column block, output-channel block); k block fastest so the workgroups that
+    // share an input patch are neighbours
+    const int kblocks = p.K / WG_KB;
+    int wg = blockIdx.x;
+    const int kb = wg % kblocks;
+    wg /= kblocks;
+    const int cb = wg % p.col_blocks;
+    const int rb = wg / p.col_blocks;
+    const int k0 = kb * WG_KB;
+
+    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
+
+    // ---- input-transform work item of this thread: tile (tid / 8), channel pair (tid % 8) ----
+    const int tt = tid >> 3, cp = tid & 7;
+    const int trow = rb * p.BTH + tt / p.BTW;          // global tile row (n * TH + th)
+    const int tcol = cb * p.BTW + tt % p.BTW;
+    const bool tile_ok = trow < p.rows_total;
+    const int n = tile_ok ? trow / p.TH : 0;
+    const int th = tile_ok ? trow - n * p.TH : 0;
+    const int ih0 = 2 * th - 1, iw0 = 2 * tcol - 1;
+    unsigned xoff[16];  // byte offsets of the 4x4 patch pixels at channel pair cp (OOB_OFF outside the image)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ih = ih0 + i, iw = iw0 + j;
+            const bool ok = tile_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            xoff[i * 4 + j] = ok ? (unsigned)((((n * p.H + ih) * p.W + iw) * p.C + cp * 2) * 4) : OOB_OFF;
+        }
+    // LDS destination of this thread's V values: position p -> p * 2048 B + tile * 64 B + swizzled channel-pair slot
+    const unsigned vdst = (unsigned)(tt * 64 + ((((cp >> 1) ^ ((tt >> 2) & 3)) << 4) | ((cp & 1) << 3)));
+    // ---- MFMA fragments ----
+    const unsigned a_src = (unsigned)(l31 * 64);                         // + position * 2048 + swizzled chunk
+    const int swz = (l31 >> 2) & 3;
+    // U fragment of this lane: U[pos][k0 + l31][c0 + 8 * khalf .. + 7]
+    const unsigned ubase = (unsigned)(((k0 + l31) * p.C + 8 * khalf) * 4);
+    const unsigned upos = (unsigned)((size_t)p.K * p.C * 4);             // bytes between positions
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    f32x2 raw[16];
+    f32x4 ub[4][2];
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, xoff[e], (unsigned)(c0 * 4), 0);
+            raw[e][0] = __uint_as_float(v[0]);
+            raw[e][1] = __uint_as_float(v[1]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(
+                    u_rsrc, ubase + (unsigned)(wave * 4 + q) * upos + (unsigned)(h * 16), (unsigned)(c0 * 4), 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ub[q][h][e] = __uint_as_float(v[e]);
+            }
+    };
+
+    const int nchunks = p.C / WG_CH;
+    prefetch(0);
+    for (int ck = 0; ck < nchunks; ++ck) {
+        // ---- input transform of the prefetched patch: V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1] ----
+        f32x2 t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0][j] = raw[0 * 4 + j] - raw[2 * 4 + j];
+            t[1][j] = raw[1 * 4 + j] + raw[2 * 4 + j];
+            t[2][j] = raw[2 * 4 + j] - raw[1 * 4 + j];
+            t[3][j] = raw[1 * 4 + j] - raw[3 * 4 + j];
+        }
+        f32x4 bcur[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { bcur[q][0] = ub[q][0]; bcur[q][1] = ub[q][1]; }
+        if (ck > 0) __syncthreads();  // every wave is done reading the previous chunk's V
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 v0 = t[i][0] - t[i][2];
+            const f32x2 v1 = t[i][1] + t[i][2];
+            const f32x2 v2 = t[i][2] - t[i][1];
+            const f32x2 v3 = t[i][1] - t[i][3];
+            float* base = lds + ((i * 4) * 2048 + vdst) / 4;
+            *reinterpret_cast<f32x2*>(base) = v0;
+            *reinterpret_cast<f32x2*>(base + 512) = v1;
+            *reinterpret_cast<f32x2*>(base + 1024) = v2;
+            *reinterpret_cast<f32x2*>(base + 1536) = v3;
+        }
+        if (ck + 1 < nchunks) prefetch((ck + 1) * WG_CH);  // flies under the MFMAs below
+        __syncthreads();
+        // ---- 4 positions x 8 MFMAs: acc[q] += V_pos[tiles][16] * U_pos[k][16]^T ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* vrow = lds + ((wave * 4 + q) * 2048 + a_src) / 4;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(vrow + (((khalf * 2 + 0) ^ swz) << 2));
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(vrow + (((khalf * 2 + 1) ^ swz) << 2));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bcur[q][0][e], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bcur[q][1][e], acc[q], 0, 0, 0);
+        }
+    }
+    // ---- output transform: M[pos][tile][k] through LDS, y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1] ----
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tile = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            lds[((wave * 4 + q) * WG_TILES + tile) * WG_KB + l31] = acc[q][r];
+        }
+    __syncthreads();
+    const int kk = tid & 31;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int tile = pass * 8 + (tid >> 5);
+        const int orow = rb * p.BTH + tile / p.BTW, ocol = cb * p.BTW + tile % p.BTW;
+        float m[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m[e] = lds[(e * WG_TILES + tile) * WG_KB + kk];
+        float s[2][4];  // A^T M
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[0][j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
+            s[1][j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
+        }
+        if (orow < p.rows_total) {
+            const int on = orow / p.TH, oth = orow - on * p.TH;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float y0 = s[i][0] + s[i][1] + s[i][2];
+                const float y1 = s[i][1] - s[i][2] - s[i][3];
+                float* o = p.y + (((size_t)(on * p.H + 2 * oth + i) * p.W + 2 * ocol) * p.K + k0 + kk);
+                if (p.accumulate) {
+                    o[0] += y0;
+                    o[p.K] += y1;
+                } else {
+                    o[0] = y0;
+                    o[p.K] = y1;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ds6g_winograd_weight_floats(int K, int C) { return (size_t)16 * K * C; }
+
+int ds6g_winograd_weights(const float* w, float* u, int K, int C, int transpose_flip, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(w && u && K > 0 && C > 0);
+    const long n = (long)K * C;
+    hipLaunchKernelGGL(winograd_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, u, K,
+                       C, transpose_flip);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+// 1 if the shape is supported by ds6g_conv3x3_winograd_fwd
+int ds6g_winograd_supported(int N, int H, int W, int C, int K) {
+    if (H % 2 || W % 2 || C % WG_CH || K % WG_KB || N <= 0) return 0;
+    const int TW = W / 2;
+    if (TW >= 8 ? TW % 8 != 0 : 32 % TW != 0) return 0;
+    const size_t xb = (size_t)N * H * W * C * 4, ub = (size_t)16 * K * C * 4;
+    return xb < OOB_OFF && ub < OOB_OFF;
+}
+
+// y[N][H][W][K] = conv3x3 (stride 1, pad 1) of x[N][H][W][C] with the filter whose Winograd transform is u
+// (ds6g_winograd_weights; transpose_flip = 1 there turns this call into the data gradient of the same conv);
+// accumulate: y += result
+int ds6g_conv3x3_winograd_fwd(const float* x, const float* u, float* y, int N, int H, int W, int C, int K, int accumulate,
+                              void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && u && y && ds6g_winograd_supported(N, H, W, C, K));
+    WinoParams p{};
+    p.x = x; p.u = u; p.y = y; p.N = N; p.H = H; p.W = W; p.C = C; p.K = K;
+    p.TH = H / 2; p.TW = W / 2;
+    p.BTW = p.TW >= 8 ? 8 : p.TW;
+    p.BTH = WG_TILES / p.BTW;
+    p.rows_total = N * p.TH;
+    p.col_blocks = p.TW / p.BTW;
+    p.x_bytes = (unsigned)((size_t)N * H * W * C * 4);
+    p.u_bytes = (unsigned)((size_t)16 * K * C * 4);
+    p.accumulate = accumulate;
+    const int row_blocks = (p.rows_total + p.BTH - 1) / p.BTH;
+    const long blocks = (long)row_blocks * p.col_blocks * (K / WG_KB);
+    hipLaunchKernelGGL(winograd_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+}  // extern "C"

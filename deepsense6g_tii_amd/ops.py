@@ -79,6 +79,30 @@ def bn_fold(w_ohwi_ptr, bn, K, taps, cin, cpad=None):
     return w_out, b_out
 
 
+def winograd_ok(x_shape, K):
+    """3x3 / stride 1 / pad 1 conv of an NHWC tensor of this shape to K channels can run as Winograd F(2x2, 3x3)"""
+    N, H, W, C = x_shape
+    return bool(lib().winograd_supported(N, H, W, C, K)) and lib().get_compute_mode() == 0
+
+
+def winograd_weights(w_ohwi_ptr, K, C, device, dgrad=False):
+    """U = G g G^T of an OHWI [K, 3, 3, C] filter: [16, K, C] (forward) or, dgrad=True, [16, C, K] of the
+    channel-swapped, 180-degree-rotated filter"""
+    u = torch.empty(lib().winograd_weight_floats(K, C), dtype=F32, device=device)
+    lib().winograd_weights(w_ohwi_ptr, _p(u), K, C, int(dgrad), _stream())
+    return u
+
+
+def conv3x3_winograd(x, u, K, out=None, accumulate=False):
+    """y (+)= conv3x3(x) (stride 1, pad 1) from the transformed filter u [16, K, C]"""
+    N, H, W, C = x.shape
+    _chk(x)
+    y = out if out is not None else torch.empty((N, H, W, K), dtype=F32, device=x.device)
+    _chk(y, N, H, W, K)
+    lib().conv3x3_winograd_fwd(_p(x), _p(u), _p(y), N, H, W, C, K, int(accumulate), _stream())
+    return y
+
+
 def conv2d_dgrad(dy, w_ohwi_ptr, x_shape, R, S, stride, pad, out=None, accumulate=False):
     N, H, W, C = x_shape
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)

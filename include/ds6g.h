@@ -63,6 +63,17 @@ int ds6g_conv2d_bias_act_fwd(const float* x, const float* w, const float* bias, 
 int ds6g_bn_fold(const float* w, const float* gamma, const float* beta, const float* running_mean,
                  const float* running_var, float eps, float* w_out, float* bias_out, int K, int taps, int cin, int cpad,
                  void* stream);
+/* ---- winograd.hip : Winograd F(2x2, 3x3) for the 3x3 / stride 1 / pad 1 convolutions of the BasicBlocks
+ * (model2_seq.py:510-512,528-530,546-548,565-567): 16 GEMMs on transformed 4x4 tiles, 2.25x fewer MFMA FLOPs.
+ * winograd_weights builds U[16][K][C] = G g G^T from the OHWI filter (transpose_flip = 1: the dgrad filter, i.e.
+ * U[16][C][K] of the channel-swapped, 180-degree-rotated filter); conv3x3_winograd_fwd computes
+ * y[N][H][W][K] (+)= conv(x[N][H][W][C]) from it (call it with dy and the dgrad filter to obtain dx).
+ * winograd_supported: H, W even, C % 16 == 0, K % 32 == 0, W/2 a multiple of 8 or a divisor of 32. */
+size_t ds6g_winograd_weight_floats(int K, int C);
+int ds6g_winograd_weights(const float* w, float* u, int K, int C, int transpose_flip, void* stream);
+int ds6g_winograd_supported(int N, int H, int W, int C, int K);
+int ds6g_conv3x3_winograd_fwd(const float* x, const float* u, float* y, int N, int H, int W, int C, int K, int accumulate,
+                              void* stream);
 /* nn.Linear of the GPT blocks with fused epilogue y = residual + dropout(act(x w^T + b)):
  * model2_seq.py:97-99 (q,k,v), :109 (proj + resid_drop), :121-126 (MLP, ReLU), :131-132 (residuals). */
 int ds6g_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int relu,

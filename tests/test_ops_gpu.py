@@ -538,3 +538,28 @@ def test_cabi_error_behaviour(dev):
     yg = ops.conv2d_fwd(xg, wg.data_ptr(), 16, 3, 3, 1, 1)
     ref = torch.nn.functional.conv2d(xg.cpu().permute(0, 3, 1, 2), wg.cpu().permute(0, 3, 1, 2), None, 1, 1)
     close(yg.cpu().permute(0, 3, 1, 2), ref, 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("N,H,W,C,K", [(2, 8, 16, 32, 32), (3, 16, 16, 64, 64), (5, 8, 8, 128, 32), (1, 64, 64, 32, 96)])
+def test_winograd_conv3x3(dev, N, H, W, C, K):
+    """Winograd F(2x2, 3x3) forward and data gradient (the same kernel on the channel-swapped, rotated filter, also
+    accumulating) against torch: exact-fp32 products, only the transform arithmetic differs -> 2e-5 of the largest value."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N * H + C)
+    x = torch.randn(N, C, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(K, C, 3, 3, generator=g) / (3 * C ** 0.5)).requires_grad_(True)
+    y = F.conv2d(x, w, None, 1, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xg = x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    wg = w.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    assert ops.winograd_ok(xg.shape, K)
+    u = ops.winograd_weights(wg.data_ptr(), K, C, dev)
+    yg = ops.conv3x3_winograd(xg, u, K)
+    close(yg.cpu().permute(0, 3, 1, 2), y.detach(), 2e-5, 2e-5)
+    dyg = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    assert ops.winograd_ok(dyg.shape, C)
+    ud = ops.winograd_weights(wg.data_ptr(), K, C, dev, dgrad=True)
+    base = torch.randn(N, H, W, C, generator=g).cuda()
+    dx = ops.conv3x3_winograd(dyg, ud, C, out=base.clone(), accumulate=True)
+    close((dx - base).cpu().permute(0, 3, 1, 2), x.grad, 2e-5, 2e-5)
