@@ -23,6 +23,7 @@
 #include <vector>
 
 extern int g_ds6g_attn_percu;  // attention.hip: split-heuristic override (timing experiments)
+extern int g_wino_kb64;         // winograd.hip: 64-channel workgroups (timing experiments)
 
 // LDS stages of the k loop (DMA runs STAGES-1 k-tiles ahead).  Measured on gfx950 (tools/bench_igemm.py): fwd / dgrad
 // gain 2-11 % from a third stage (more bytes in flight per CU outweigh 8 -> 6 resident workgroups), wgrad (128x64
@@ -877,6 +878,7 @@ int ds6g_profile_end(int* variants, double* flops, float* ms, int cap) {
 int ds6g_set_debug_flags(int flags) {
     g_dbg = flags & 0xbf;  // 0x80: force the general (FAST 0) walk
     g_ds6g_attn_percu = (flags >> 20) & 0xf;  // attention: resident-workgroups-per-CU assumption of the split heuristic
+    g_wino_kb64 = (flags & 0x02000000) ? 1 : 0;
     g_bf16_bk32 = (flags & 0x10000000) ? 0 : 1;
     g_f32_bk32 = (flags & 0x20000000) ? 1 : ((flags & 0x40000000) ? 0 : 2);   // fp32 32-column k-tiles: everywhere / never
     g_wgrad_tile = (flags & 0x40) ? 2 : 1;

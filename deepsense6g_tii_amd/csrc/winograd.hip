@@ -15,16 +15,19 @@
 // global -> registers directly in fragment layout (each wave needs only its own 4 positions: nothing to share).
 // The next chunk's patch and U fragments are prefetched into registers while the MFMAs of the current chunk run.
 #include "common.h"
+#include <cstdlib>
+
+int g_wino_kb64 = 0;  // timing experiments: 64 output channels per workgroup, one wave per SIMD (measured slower)
 
 namespace {
 
 constexpr int WG_TILES = 32;   // tiles per workgroup (MFMA rows)
-constexpr int WG_KB = 32;      // output channels per workgroup (MFMA columns)
+constexpr int WG_KB = 32;      // output channels per MFMA column block (a workgroup owns TNK of them)
 constexpr int WG_CH = 16;      // channels per chunk
 
 struct WinoParams {
     const float* x;      // [N][H][W][C]
-    const float* u;      // [16][K][C]
+    const float* u;      // [16][K/32][C/16] fragments of 64 lanes x 8 floats (see winograd_weights_kernel)
     float* y;            // [N][H][W][K]
     int N, H, W, C, K;
     int TH, TW;          // tiles per image column / row (H/2, W/2)
@@ -32,6 +35,7 @@ struct WinoParams {
     int rows_total;      // N * TH  (tile rows over the whole batch)
     int col_blocks;      // TW / BTW
     unsigned x_bytes, u_bytes;
+    int dbg;             // timing ablations (DS6G_WINO_DBG): 1 no patch loads, 2 no U loads, 4 no transform/store, 8 no MFMA
     int accumulate;      // y += result (data gradient summed onto the gradient of the residual branch)
 };
 
@@ -58,36 +62,43 @@ __global__ __launch_bounds__(256) void winograd_weights_kernel(const float* __re
         t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
         t[3][s] = g[2][s];
     }
+    // stored in MFMA B-fragment order: for position p, 32-row block kb, 16-column chunk cc the 512 values sit as
+    // [lane = row + 32 * (col / 8)][col % 8], so a wave reads its fragment of a chunk as two fully coalesced 1 KiB loads
+    const size_t frag = ((size_t)(ko >> 5) * (Co >> 4) + (co >> 4)) * 512 + (size_t)(((ko & 31) + 32 * ((co >> 3) & 1)) * 8 + (co & 7));
+    const size_t pstride = (size_t)Ko * Co;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float o0 = t[r][0];
         const float o1 = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
         const float o2 = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
         const float o3 = t[r][2];
-        const size_t base = ((size_t)(r * 4) * Ko + ko) * Co + co;
+        const size_t base = (size_t)(r * 4) * pstride + frag;
         u[base] = o0;
-        u[base + (size_t)Ko * Co] = o1;
-        u[base + 2 * (size_t)Ko * Co] = o2;
-        u[base + 3 * (size_t)Ko * Co] = o3;
+        u[base + pstride] = o1;
+        u[base + 2 * pstride] = o2;
+        u[base + 3 * pstride] = o3;
     }
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256, 2) void winograd_fwd_kernel(const WinoParams p) {
-    // V image: [16 positions][32 tiles][16 ch] (2 KiB per position); reused as M [16][32 tiles][32 k] at the end
+// TNK = 32-channel output blocks per workgroup.  TNK = 2 (one wave per SIMD, 64 MFMAs per wave and chunk) gives the
+// register prefetch of the next chunk twice the time to land and halves the redundant input transforms.
+template <int TNK>
+__global__ __launch_bounds__(256, (TNK == 1 ? 2 : 1)) void winograd_fwd_kernel(const WinoParams p) {
+    // two V images of [16 positions][32 tiles][16 ch] (2 KiB per position) = 64 KiB; reused as M [16][32 tiles][32 k]
     __shared__ __attribute__((aligned(16))) float lds[16 * WG_TILES * WG_KB];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, khalf = lane >> 5;
     // workgroup -> (tile-row block, tile-column block, output-channel block); k block fastest so the workgroups that
     // share an input patch are neighbours
-    const int kblocks = p.K / WG_KB;
+    const int kblocks = p.K / (WG_KB * TNK);
     int wg = blockIdx.x;
     const int kb = wg % kblocks;
     wg /= kblocks;
     const int cb = wg % p.col_blocks;
     const int rb = wg / p.col_blocks;
-    const int k0 = kb * WG_KB;
+    const int k0 = kb * WG_KB * TNK;
 
     const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
@@ -114,40 +125,48 @@ __global__ __launch_bounds__(256, 2) void winograd_fwd_kernel(const WinoParams p
     // ---- MFMA fragments ----
     const unsigned a_src = (unsigned)(l31 * 64);                         // + position * 2048 + swizzled chunk
     const int swz = (l31 >> 2) & 3;
-    // U fragment of this lane: U[pos][k0 + l31][c0 + 8 * khalf .. + 7]
-    const unsigned ubase = (unsigned)(((k0 + l31) * p.C + 8 * khalf) * 4);
+    // U fragment of this lane: 8 floats at [pos][k0 / 32 (+j)][chunk][lane] (fragment-ordered by winograd_weights_kernel)
+    const unsigned ubase = (unsigned)((((k0 >> 5) * (p.C >> 4)) * 512 + lane * 8) * 4);
     const unsigned upos = (unsigned)((size_t)p.K * p.C * 4);             // bytes between positions
 
-    f32x16 acc[4];
+    f32x16 acc[4][TNK];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+        for (int j = 0; j < TNK; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][j][r] = 0.f;
 
     f32x2 raw[16];
-    f32x4 ub[4][2];
+    f32x4 ub[4][TNK][2];
     auto prefetch = [&](int c0) {
+        if (!(p.dbg & 1))
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const auto v = __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, xoff[e], (unsigned)(c0 * 4), 0);
             raw[e][0] = __uint_as_float(v[0]);
             raw[e][1] = __uint_as_float(v[1]);
         }
+        if (!(p.dbg & 2))
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(
-                    u_rsrc, ubase + (unsigned)(wave * 4 + q) * upos + (unsigned)(h * 16), (unsigned)(c0 * 4), 0);
+            for (int j = 0; j < TNK; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ub[q][h][e] = __uint_as_float(v[e]);
-            }
+                for (int h = 0; h < 2; ++h) {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(
+                        u_rsrc, ubase + (unsigned)(wave * 4 + q) * upos + (unsigned)(j * (p.C >> 4) * 2048 + h * 16),
+                        (unsigned)((c0 >> 4) * 2048), 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ub[q][j][h][e] = __uint_as_float(v[e]);
+                }
     };
 
     const int nchunks = p.C / WG_CH;
-    prefetch(0);
-    for (int ck = 0; ck < nchunks; ++ck) {
-        // ---- input transform of the prefetched patch: V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1] ----
+    // input transform of the prefetched patch, V = B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], written to
+    // V buffer `vb` (two buffers: the transform of chunk c+1 is written while other waves still multiply chunk c)
+    auto transform_store = [&](int vb) {
+        if (p.dbg & 4) return;
         f32x2 t[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -156,75 +175,99 @@ __global__ __launch_bounds__(256, 2) void winograd_fwd_kernel(const WinoParams p
             t[2][j] = raw[2 * 4 + j] - raw[1 * 4 + j];
             t[3][j] = raw[1 * 4 + j] - raw[3 * 4 + j];
         }
-        f32x4 bcur[4][2];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { bcur[q][0] = ub[q][0]; bcur[q][1] = ub[q][1]; }
-        if (ck > 0) __syncthreads();  // every wave is done reading the previous chunk's V
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const f32x2 v0 = t[i][0] - t[i][2];
             const f32x2 v1 = t[i][1] + t[i][2];
             const f32x2 v2 = t[i][2] - t[i][1];
             const f32x2 v3 = t[i][1] - t[i][3];
-            float* base = lds + ((i * 4) * 2048 + vdst) / 4;
+            float* base = lds + vb * (16 * 512) + ((i * 4) * 2048 + vdst) / 4;
             *reinterpret_cast<f32x2*>(base) = v0;
             *reinterpret_cast<f32x2*>(base + 512) = v1;
             *reinterpret_cast<f32x2*>(base + 1024) = v2;
             *reinterpret_cast<f32x2*>(base + 1536) = v3;
         }
-        if (ck + 1 < nchunks) prefetch((ck + 1) * WG_CH);  // flies under the MFMAs below
-        __syncthreads();
+    };
+    prefetch(0);
+    transform_store(0);
+    f32x4 bcur[4][TNK][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < TNK; ++j) { bcur[q][j][0] = ub[q][j][0]; bcur[q][j][1] = ub[q][j][1]; }
+    __syncthreads();
+    for (int ck = 0; ck < nchunks; ++ck) {
+        const bool more = ck + 1 < nchunks;
+        if (more) prefetch((ck + 1) * WG_CH);  // patch + U fragments of the next chunk fly under the MFMAs below
         // ---- 4 positions x 8 MFMAs: acc[q] += V_pos[tiles][16] * U_pos[k][16]^T ----
+        const float* vbuf = lds + (ck & 1) * (16 * 512);
+        if (!(p.dbg & 8))
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float* vrow = lds + ((wave * 4 + q) * 2048 + a_src) / 4;
+            const float* vrow = vbuf + ((wave * 4 + q) * 2048 + a_src) / 4;
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(vrow + (((khalf * 2 + 0) ^ swz) << 2));
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(vrow + (((khalf * 2 + 1) ^ swz) << 2));
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bcur[q][0][e], acc[q], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < TNK; ++j)
+                    acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bcur[q][j][0][e], acc[q][j], 0, 0, 0);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bcur[q][1][e], acc[q], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < TNK; ++j)
+                    acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bcur[q][j][1][e], acc[q][j], 0, 0, 0);
         }
+        if (more) {
+            transform_store((ck + 1) & 1);  // the other buffer: last read one chunk ago, behind the barrier below
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < TNK; ++j) { bcur[q][j][0] = ub[q][j][0]; bcur[q][j][1] = ub[q][j][1]; }
+        }
+        __syncthreads();
     }
-    // ---- output transform: M[pos][tile][k] through LDS, y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1] ----
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tile = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            lds[((wave * 4 + q) * WG_TILES + tile) * WG_KB + l31] = acc[q][r];
-        }
-    __syncthreads();
+    // ---- output transform: M[pos][tile][k] through LDS (one 32-channel block at a time), y = A^T M A,
+    //      A^T = [1 1 1 0; 0 1 -1 -1] ----
     const int kk = tid & 31;
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int tile = pass * 8 + (tid >> 5);
-        const int orow = rb * p.BTH + tile / p.BTW, ocol = cb * p.BTW + tile % p.BTW;
-        float m[16];
+    for (int j = 0; j < TNK; ++j) {
+        if (j > 0) __syncthreads();  // the previous block's M has been consumed
 #pragma unroll
-        for (int e = 0; e < 16; ++e) m[e] = lds[(e * WG_TILES + tile) * WG_KB + kk];
-        float s[2][4];  // A^T M
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[0][j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
-            s[1][j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
-        }
-        if (orow < p.rows_total) {
-            const int on = orow / p.TH, oth = orow - on * p.TH;
+            for (int r = 0; r < 16; ++r) {
+                const int tile = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                lds[((wave * 4 + q) * WG_TILES + tile) * WG_KB + l31] = acc[q][j][r];
+            }
+        __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float y0 = s[i][0] + s[i][1] + s[i][2];
-                const float y1 = s[i][1] - s[i][2] - s[i][3];
-                float* o = p.y + (((size_t)(on * p.H + 2 * oth + i) * p.W + 2 * ocol) * p.K + k0 + kk);
-                if (p.accumulate) {
-                    o[0] += y0;
-                    o[p.K] += y1;
-                } else {
-                    o[0] = y0;
-                    o[p.K] = y1;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int tile = pass * 8 + (tid >> 5);
+            const int orow = rb * p.BTH + tile / p.BTW, ocol = cb * p.BTW + tile % p.BTW;
+            float m[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) m[e] = lds[(e * WG_TILES + tile) * WG_KB + kk];
+            float sr[2][4];  // A^T M
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                sr[0][c] = m[0 * 4 + c] + m[1 * 4 + c] + m[2 * 4 + c];
+                sr[1][c] = m[1 * 4 + c] - m[2 * 4 + c] - m[3 * 4 + c];
+            }
+            if (orow < p.rows_total) {
+                const int on = orow / p.TH, oth = orow - on * p.TH;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float y0 = sr[i][0] + sr[i][1] + sr[i][2];
+                    const float y1 = sr[i][1] - sr[i][2] - sr[i][3];
+                    float* o = p.y + (((size_t)(on * p.H + 2 * oth + i) * p.W + 2 * ocol) * p.K + k0 + j * WG_KB + kk);
+                    if (p.accumulate) {
+                        o[0] += y0;
+                        o[p.K] += y1;
+                    } else {
+                        o[0] = y0;
+                        o[p.K] = y1;
+                    }
                 }
             }
         }
@@ -273,9 +316,15 @@ int ds6g_conv3x3_winograd_fwd(const float* x, const float* u, float* y, int N, i
     p.x_bytes = (unsigned)((size_t)N * H * W * C * 4);
     p.u_bytes = (unsigned)((size_t)16 * K * C * 4);
     p.accumulate = accumulate;
+    { const char* e = getenv("DS6G_WINO_DBG"); p.dbg = e ? atoi(e) : 0; }
     const int row_blocks = (p.rows_total + p.BTH - 1) / p.BTH;
-    const long blocks = (long)row_blocks * p.col_blocks * (K / WG_KB);
-    hipLaunchKernelGGL(winograd_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    if (K % (2 * WG_KB) == 0 && g_wino_kb64) {
+        const long blocks = (long)row_blocks * p.col_blocks * (K / (2 * WG_KB));
+        hipLaunchKernelGGL(winograd_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        const long blocks = (long)row_blocks * p.col_blocks * (K / WG_KB);
+        hipLaunchKernelGGL(winograd_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    }
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }

@@ -8,6 +8,7 @@ from deepsense6g_tii_amd._lib import lib
 
 dev = torch.device("cuda:0")
 L = lib()
+L.set_debug_flags(int(os.environ.get('DBG', '0')))
 st = torch.cuda.current_stream().cuda_stream
 reps = int(os.environ.get("REPS", "20"))
 
@@ -23,7 +24,7 @@ def timeit(fn):
 
 print(f"{'shape':22s} {'direct us':>10s} {'wino us':>9s} {'wino+U us':>10s} {'max rel err':>12s}")
 for name, N, H, C, K in (("l1 64x64 c64", 60, 64, 64, 64), ("l2 32x32 c128", 60, 32, 128, 128), ("l3 16x16 c256", 60, 16, 256, 256),
-                         ("l4 8x8 c512", 60, 8, 512, 512), ("small 8x16", 3, 8, 16, 32)):
+                         ("l4 8x8 c512", 60, 8, 512, 512), ("small 8x8", 3, 8, 32, 32)):
     x = torch.randn(N, H, H, C, device=dev)
     w = torch.randn(K, 3, 3, C, device=dev) * (1.0 / (3 * C ** 0.5))
     assert L.winograd_supported(N, H, H, C, K), name
