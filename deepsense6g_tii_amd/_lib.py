@@ -68,7 +68,7 @@ class _Lib:
                 raise Ds6gError(f"libds6g.so does not export {name} declared in include/ds6g.h") from e
             fn.restype = restype
             fn.argtypes = argtypes
-            if restype is ctypes.c_int and name not in ("ds6g_version", "ds6g_last_igemm_variant", "ds6g_get_compute_mode", "ds6g_profile_end", "ds6g_winograd_supported"):
+            if restype is ctypes.c_int and name not in ("ds6g_version", "ds6g_last_igemm_variant", "ds6g_get_compute_mode", "ds6g_profile_end", "ds6g_winograd_supported", "ds6g_winograd_wgrad_supported"):
                 setattr(self, name[len("ds6g_"):], self._checked(fn, name))
             else:
                 setattr(self, name[len("ds6g_"):], fn)

@@ -274,6 +274,208 @@ __global__ __launch_bounds__(256, (TNK == 1 ? 2 : 1)) void winograd_fwd_kernel(c
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the same convolutions in the Winograd domain: the forward is linear in U = G g G^T, so
+//     dU_p[k][c] = sum_tiles E_p[tile][k] * V_p[tile][c],   E = A dY A^T (2x2 -> 4x4),   V = B^T d B,
+//     dW = G^T dU G   (4x4 -> 3x3, winograd_wgrad_finish_kernel, which also sums the split slabs)
+// - 16 GEMMs whose reduction runs over the tiles: 4 MFMA FLOPs per pixel, channel pair and filter instead of 9.
+// One workgroup = one row i of the 4x4 positions (blockIdx.y; wave j owns position (i, j)), 64 output x 64 input
+// channels, one split of the tile range.  Row i of B^T / A touches only two input rows / one or two dy rows, so the
+// four row-workgroups of a tile share no transform arithmetic.  Per chunk of 16 tiles every thread transforms one
+// (tile, 4-channel) item of x and one of dy in registers and writes them to the tile-major LDS images the MFMA
+// fragments are read from (ds_read_b32, consecutive lanes = consecutive channels), double-buffered, the next chunk's
+// pixels prefetched into registers under the MFMAs.
+struct WinoWgradParams {
+    const float* x;    // [N][H][W][C]
+    const float* dy;   // [N][H][W][K]
+    float* du;         // [splits][16][K][C]
+    int N, H, W, C, K, TH, TW;
+    int tiles_total, tiles_per_split;  // tiles_per_split is a multiple of 16
+    unsigned x_bytes, dy_bytes;
+};
+
+constexpr int WW_T = 16;   // tiles per chunk (MFMA reduction depth)
+constexpr int WW_KB = 64, WW_CB = 64;
+
+__global__ __launch_bounds__(256, 2) void winograd_wgrad_kernel(const WinoWgradParams p) {
+    __shared__ __attribute__((aligned(16))) float Es[2][4][WW_T][WW_KB];  // [buffer][j][tile][k]
+    __shared__ __attribute__((aligned(16))) float Vs[2][4][WW_T][WW_CB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int cblocks = p.C / WW_CB;
+    const int k0 = (blockIdx.x / cblocks) * WW_KB, c0 = (blockIdx.x % cblocks) * WW_CB;
+    const int ri = blockIdx.y;          // row i of the position grid
+    const int split = blockIdx.z;
+    const int tbeg = split * p.tiles_per_split;
+    const int tend = min(p.tiles_total, tbeg + p.tiles_per_split);
+    const int nchunks = (tend - tbeg + WW_T - 1) / WW_T;
+
+    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
+    // rows of the 4x4 patch row i of B^T combines: t = d[ra] + sb * d[rb];  rows of the 2x2 dy tile row i of A combines
+    const int ra = (ri == 0) ? 0 : (ri == 2 ? 2 : 1);
+    const int rb = (ri == 3) ? 3 : (ri == 2 ? 1 : 2);
+    const float sb = (ri == 1) ? 1.f : -1.f;
+    // e = ya * dy[0] + yb * dy[1]
+    const float ya = (ri == 3) ? 0.f : 1.f;
+    const float yb = (ri == 0) ? 0.f : (ri == 1 ? 1.f : -1.f);
+
+    // transform work item: tile (tid / 16) of the chunk, channel quad (tid % 16)
+    const int tt = tid >> 4, qd = tid & 15;
+    int tile = tbeg + tt;  // running tile index of this thread
+    int tn, tth, ttw;
+    {
+        const int per_img = p.TH * p.TW;
+        tn = tile / per_img;
+        const int rem = tile - tn * per_img;
+        tth = rem / p.TW;
+        ttw = rem - tth * p.TW;
+    }
+    f32x4 xr[8], yr[4];
+    auto prefetch = [&]() {
+        const bool ok = tile < tend;
+        const int ih0 = 2 * tth - 1, iw0 = 2 * ttw - 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ih = ih0 + (h ? rb : ra);
+            const bool rok = ok && (unsigned)ih < (unsigned)p.H;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int iw = iw0 + b;
+                const unsigned off = (rok && (unsigned)iw < (unsigned)p.W)
+                                         ? (unsigned)((((tn * p.H + ih) * p.W + iw) * p.C + c0 + qd * 4) * 4) : OOB_OFF;
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xr[h * 4 + b][e] = __uint_as_float(v[e]);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const unsigned off = ok ? (unsigned)((((tn * p.H + 2 * tth + a) * p.W + 2 * ttw + b) * p.K + k0 + qd * 4) * 4)
+                                        : OOB_OFF;
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, off, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) yr[a * 2 + b][e] = __uint_as_float(v[e]);
+            }
+        // advance to the same slot of the next chunk
+        tile += WW_T;
+        ttw += WW_T;
+        while (ttw >= p.TW) {
+            ttw -= p.TW;
+            if (++tth == p.TH) { tth = 0; ++tn; }
+        }
+    };
+    auto transform_store = [&](int buf) {
+        f32x4 t[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) t[b] = xr[b] + sb * xr[4 + b];
+        f32x4* vd = reinterpret_cast<f32x4*>(&Vs[buf][0][tt][qd * 4]);
+        constexpr int PS = WW_T * WW_CB / 4;  // f32x4 stride between positions j
+        vd[0] = t[0] - t[2];
+        vd[PS] = t[1] + t[2];
+        vd[2 * PS] = t[2] - t[1];
+        vd[3 * PS] = t[1] - t[3];
+        const f32x4 e0 = ya * yr[0] + yb * yr[2], e1 = ya * yr[1] + yb * yr[3];
+        f32x4* ed = reinterpret_cast<f32x4*>(&Es[buf][0][tt][qd * 4]);
+        constexpr int QS = WW_T * WW_KB / 4;
+        ed[0] = e0;
+        ed[QS] = e0 + e1;
+        ed[2 * QS] = e0 - e1;
+        ed[3 * QS] = -e1;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nchunks > 0) {
+        prefetch();
+        transform_store(0);
+    }
+    __syncthreads();
+    for (int ck = 0; ck < nchunks; ++ck) {
+        const bool more = ck + 1 < nchunks;
+        if (more) prefetch();
+        const float* Eb = &Es[ck & 1][wave][0][0];
+        const float* Vb = &Vs[ck & 1][wave][0][0];
+        float af[2][8], bf[2][8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                af[i][kk] = Eb[(khalf * 8 + kk) * WW_KB + i * 32 + l31];
+                bf[i][kk] = Vb[(khalf * 8 + kk) * WW_CB + i * 32 + l31];
+            }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+        if (more) transform_store((ck + 1) & 1);
+        __syncthreads();
+    }
+    // dU slab: [split][pos = 4 * ri + wave][k][c]
+    float* out = p.du + ((size_t)split * 16 + (size_t)(ri * 4 + wave)) * p.K * p.C;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                out[(size_t)k * p.C + c0 + j * 32 + l31] = acc[i][j][r];
+            }
+}
+
+// dW[k][r][s][c] (+)= (G^T (sum_splits dU) G)[r][s],  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
+__global__ __launch_bounds__(256) void winograd_wgrad_finish_kernel(const float* __restrict__ du, float* __restrict__ dw,
+                                                                    int K, int C, int splits, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)K * C) return;
+    const int k = (int)(i / C), c = (int)(i - (long)k * C);
+    float m[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) m[e] = 0.f;
+    const size_t pstride = (size_t)K * C;
+    for (int s = 0; s < splits; ++s) {
+        const float* src = du + (size_t)s * 16 * pstride + i;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m[e] += src[(size_t)e * pstride];
+    }
+    float t[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[0][j] = m[0 * 4 + j] + 0.5f * (m[1 * 4 + j] + m[2 * 4 + j]);
+        t[1][j] = 0.5f * (m[1 * 4 + j] - m[2 * 4 + j]);
+        t[2][j] = 0.5f * (m[1 * 4 + j] + m[2 * 4 + j]) + m[3 * 4 + j];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float g0 = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+        const float g1 = 0.5f * (t[r][1] - t[r][2]);
+        const float g2 = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+        float* o = dw + (((size_t)k * 3 + r) * 3) * C + c;
+        if (accumulate) {
+            o[0] += g0;
+            o[C] += g1;
+            o[2 * (size_t)C] += g2;
+        } else {
+            o[0] = g0;
+            o[C] = g1;
+            o[2 * (size_t)C] = g2;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -325,6 +527,48 @@ int ds6g_conv3x3_winograd_fwd(const float* x, const float* u, float* y, int N, i
         const long blocks = (long)row_blocks * p.col_blocks * (K / WG_KB);
         hipLaunchKernelGGL(winograd_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     }
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+// 1 if ds6g_conv3x3_winograd_wgrad supports the shape
+int ds6g_winograd_wgrad_supported(int N, int H, int W, int C, int K) {
+    if (H % 2 || W % 2 || C % WW_CB || K % WW_KB || N <= 0) return 0;
+    const size_t xb = (size_t)N * H * W * C * 4, yb = (size_t)N * H * W * K * 4;
+    return xb < OOB_OFF && yb < OOB_OFF;
+}
+
+// dw[K][3][3][C] (+)= weight gradient of the 3x3 / stride 1 / pad 1 conv from x [N][H][W][C] and dy [N][H][W][K];
+// ws holds the per-split dU slabs (any size >= one slab of 16*K*C floats; more allows more splits)
+int ds6g_conv3x3_winograd_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K,
+                                int accumulate, float* ws, size_t ws_bytes, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && dy && dw && ws && ds6g_winograd_wgrad_supported(N, H, W, C, K));
+    const size_t slab = (size_t)16 * K * C * sizeof(float);
+    DS6G_CHECK_ARG(ws_bytes >= slab);
+    WinoWgradParams p{};
+    p.x = x; p.dy = dy; p.du = ws; p.N = N; p.H = H; p.W = W; p.C = C; p.K = K;
+    p.TH = H / 2; p.TW = W / 2;
+    p.tiles_total = N * p.TH * p.TW;
+    p.x_bytes = (unsigned)((size_t)N * H * W * C * 4);
+    p.dy_bytes = (unsigned)((size_t)N * H * W * K * 4);
+    const int base = (K / WW_KB) * (C / WW_CB) * 4;
+    const int chunks = (p.tiles_total + WW_T - 1) / WW_T;
+    // ~1024 workgroups, at least 12 chunks per split, bounded by the scratch
+    long splits = (1024 + base - 1) / base;
+    if (splits > chunks / 12) splits = chunks / 12;
+    const long by_ws = (long)(ws_bytes / slab);
+    if (splits > by_ws) splits = by_ws;
+    if (splits < 1) splits = 1;
+    const int cps = (int)((chunks + splits - 1) / splits);
+    p.tiles_per_split = cps * WW_T;
+    splits = (chunks + cps - 1) / cps;
+    hipLaunchKernelGGL(winograd_wgrad_kernel, dim3((unsigned)((K / WW_KB) * (C / WW_CB)), 4, (unsigned)splits), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    DS6G_LAUNCH_CHECK();
+    const long n = (long)K * C;
+    hipLaunchKernelGGL(winograd_wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)ws, dw, K, C, (int)splits, accumulate);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }

@@ -758,6 +758,12 @@ class TransFuser(nn.Module):
     # ================================================================ backward walk =============
     def _wgrad_conv(self, conv, x, dy, R, stride, pad):
         gp, acc = self._g(conv.weight)
+        K = dy.shape[-1]
+        if (R == 3 and stride == 1 and self.use_winograd and x.shape[-1] * K >= 128 * 128
+                and ops.winograd_wgrad_ok(x.shape, K)):
+            # Winograd-domain weight gradient (measured faster from 128 x 128 channels up; 64 x 64 stays direct)
+            self._wg_launch(lambda: ops.conv3x3_winograd_wgrad(x, dy, gp, self._ws, accumulate=bool(acc)), (x, dy))
+            return
         self._wg_launch(lambda: ops.conv2d_wgrad(x, dy, gp, R, R, stride, pad, self._ws, accumulate=bool(acc)), (x, dy))
 
     # Weight gradients feed nothing but the optimizer, while the dgrad / attention / LayerNorm kernels around them form

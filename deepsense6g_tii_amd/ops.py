@@ -103,6 +103,20 @@ def conv3x3_winograd(x, u, K, out=None, accumulate=False):
     return y
 
 
+def winograd_wgrad_ok(x_shape, K):
+    N, H, W, C = x_shape
+    return bool(lib().winograd_wgrad_supported(N, H, W, C, K)) and lib().get_compute_mode() == 0
+
+
+def conv3x3_winograd_wgrad(x, dy, dw_ohwi_ptr, ws: Workspace, accumulate=False):
+    """dw [K, 3, 3, C] (+)= weight gradient of the 3x3 / stride 1 / pad 1 conv, computed in the Winograd domain"""
+    N, H, W, C = x.shape
+    K = dy.shape[3]
+    _chk(x)
+    _chk(dy, N, H, W, K)
+    lib().conv3x3_winograd_wgrad(_p(x), _p(dy), dw_ohwi_ptr, N, H, W, C, K, int(accumulate), ws.ptr, ws.nbytes, _stream())
+
+
 def conv2d_dgrad(dy, w_ohwi_ptr, x_shape, R, S, stride, pad, out=None, accumulate=False):
     N, H, W, C = x_shape
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)

@@ -74,6 +74,12 @@ int ds6g_winograd_weights(const float* w, float* u, int K, int C, int transpose_
 int ds6g_winograd_supported(int N, int H, int W, int C, int K);
 int ds6g_conv3x3_winograd_fwd(const float* x, const float* u, float* y, int N, int H, int W, int C, int K, int accumulate,
                               void* stream);
+/* weight gradient of the same convs in the Winograd domain (dU = sum_tiles (A dY A^T) (B^T d B), dW = G^T dU G): 4 MFMA
+ * FLOPs per pixel / channel pair / filter instead of 9.  ws: scratch for the per-split dU slabs (>= 16*K*C floats; more
+ * allows more splits).  Supported: H, W even, C and K multiples of 64. */
+int ds6g_winograd_wgrad_supported(int N, int H, int W, int C, int K);
+int ds6g_conv3x3_winograd_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K,
+                                int accumulate, float* ws, size_t ws_bytes, void* stream);
 /* nn.Linear of the GPT blocks with fused epilogue y = residual + dropout(act(x w^T + b)):
  * model2_seq.py:97-99 (q,k,v), :109 (proj + resid_drop), :121-126 (MLP, ReLU), :131-132 (residuals). */
 int ds6g_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int relu,

@@ -563,3 +563,26 @@ def test_winograd_conv3x3(dev, N, H, W, C, K):
     base = torch.randn(N, H, W, C, generator=g).cuda()
     dx = ops.conv3x3_winograd(dyg, ud, C, out=base.clone(), accumulate=True)
     close((dx - base).cpu().permute(0, 3, 1, 2), x.grad, 2e-5, 2e-5)
+
+
+@pytest.mark.parametrize("N,H,W,C,K", [(2, 8, 16, 64, 64), (3, 16, 16, 128, 64), (5, 6, 10, 64, 192)])
+def test_winograd_wgrad3x3(dev, N, H, W, C, K):
+    """Winograd-domain weight gradient (dU = sum_tiles E V, dW = G^T dU G, split over the tile range) against torch,
+    plain and accumulating."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N + H + C)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = (torch.randn(K, C, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    dy = torch.randn(N, K, H, W, generator=g)
+    F.conv2d(x, w, None, 1, 1).backward(dy)
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+    dyg = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    assert ops.winograd_wgrad_ok(xg.shape, K)
+    ws = ops.Workspace(dev, 256 << 20)
+    dw = torch.full((K, 3, 3, C), float("nan"), device=dev)
+    ops.conv3x3_winograd_wgrad(xg, dyg, dw.data_ptr(), ws)
+    close(dw.cpu().permute(0, 3, 1, 2), w.grad, 2e-5, 2e-5)
+    base = torch.randn(K, 3, 3, C, generator=g).cuda()
+    acc = base.clone()
+    ops.conv3x3_winograd_wgrad(xg, dyg, acc.data_ptr(), ws, accumulate=True)
+    close((acc - base).cpu().permute(0, 3, 1, 2), w.grad, 2e-5, 2e-5)

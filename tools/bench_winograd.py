@@ -52,3 +52,18 @@ for name, N, H, C, K in (("l1 64x64 c64", 60, 64, 64, 64), ("l2 32x32 c128", 60,
     tw = timeit(lambda: wino(False))
     twu = timeit(lambda: wino(True))
     print(f"{name:22s} {td:10.1f} {tw:9.1f} {twu:10.1f} {err:12.2e}  dgrad err {derr:.2e}", flush=True)
+
+print("\nweight gradient: direct vs Winograd")
+ws = ops.Workspace(dev, 1 << 30)
+for name, N, H, C, K in (("l1 64x64 c64", 60, 64, 64, 64), ("l2 32x32 c128", 60, 32, 128, 128), ("l3 16x16 c256", 60, 16, 256, 256),
+                         ("l4 8x8 c512", 60, 8, 512, 512)):
+    x = torch.randn(N, H, H, C, device=dev)
+    dy = torch.randn(N, H, H, K, device=dev)
+    d1 = torch.empty(K, 3, 3, C, device=dev)
+    d2 = torch.empty(K, 3, 3, C, device=dev)
+    ops.conv2d_wgrad(x, dy, d1.data_ptr(), 3, 3, 1, 1, ws)
+    ops.conv3x3_winograd_wgrad(x, dy, d2.data_ptr(), ws)
+    err = ((d1 - d2).abs().max() / d1.abs().max()).item()
+    t1 = timeit(lambda: ops.conv2d_wgrad(x, dy, d1.data_ptr(), 3, 3, 1, 1, ws))
+    t2 = timeit(lambda: ops.conv3x3_winograd_wgrad(x, dy, d2.data_ptr(), ws))
+    print(f"{name:22s} {t1:10.1f} {t2:9.1f}   max rel err {err:.2e}", flush=True)
