@@ -875,6 +875,26 @@ int ds6g_profile_end(int* variants, double* flops, float* ms, int cap) {
     g_prof_cap = 0;
     return n;
 }
+
+}  // extern "C"
+
+// shared with winograd.hip: open / close one profiler record around a kernel launch (no-ops unless profiling is on)
+void* ds6g_prof_open(int variant, double flops, hipStream_t st) {
+    if (!g_prof || g_prof->size() >= g_prof_cap) return nullptr;
+    g_prof->push_back(ProfRec{});
+    ProfRec* rec = &g_prof->back();
+    rec->variant = variant;
+    rec->flops = flops;
+    (void)hipEventCreate(&rec->e0);
+    (void)hipEventCreate(&rec->e1);
+    (void)hipEventRecord(rec->e0, st);
+    return rec;
+}
+void ds6g_prof_close(void* rec, hipStream_t st) {
+    if (rec) (void)hipEventRecord(static_cast<ProfRec*>(rec)->e1, st);
+}
+
+extern "C" {
 int ds6g_set_debug_flags(int flags) {
     g_dbg = flags & 0xbf;  // 0x80: force the general (FAST 0) walk
     g_ds6g_attn_percu = (flags >> 20) & 0xf;  // attention: resident-workgroups-per-CU assumption of the split heuristic

@@ -17,6 +17,10 @@
 #include "common.h"
 #include <cstdlib>
 
+// bench instrumentation shared with igemm.hip (ds6g_profile_begin / _end)
+void* ds6g_prof_open(int variant, double flops, hipStream_t st);
+void ds6g_prof_close(void* rec, hipStream_t st);
+
 int g_wino_kb64 = 0;  // timing experiments: 64 output channels per workgroup, one wave per SIMD (measured slower)
 
 namespace {
@@ -520,6 +524,8 @@ int ds6g_conv3x3_winograd_fwd(const float* x, const float* u, float* y, int N, i
     p.accumulate = accumulate;
     { const char* e = getenv("DS6G_WINO_DBG"); p.dbg = e ? atoi(e) : 0; }
     const int row_blocks = (p.rows_total + p.BTH - 1) / p.BTH;
+    // profiler variant 20000: forward / data gradient; flops = those of the direct 3x3 convolution it replaces
+    void* rec = ds6g_prof_open(20000, 2.0 * N * H * W * (double)K * 9.0 * C, (hipStream_t)stream);
     if (K % (2 * WG_KB) == 0 && g_wino_kb64) {
         const long blocks = (long)row_blocks * p.col_blocks * (K / (2 * WG_KB));
         hipLaunchKernelGGL(winograd_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
@@ -527,6 +533,7 @@ int ds6g_conv3x3_winograd_fwd(const float* x, const float* u, float* y, int N, i
         const long blocks = (long)row_blocks * p.col_blocks * (K / WG_KB);
         hipLaunchKernelGGL(winograd_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     }
+    ds6g_prof_close(rec, (hipStream_t)stream);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }
@@ -563,8 +570,10 @@ int ds6g_conv3x3_winograd_wgrad(const float* x, const float* dy, float* dw, int 
     const int cps = (int)((chunks + splits - 1) / splits);
     p.tiles_per_split = cps * WW_T;
     splits = (chunks + cps - 1) / cps;
+    void* rec = ds6g_prof_open(20001, 2.0 * N * H * W * (double)K * 9.0 * C, (hipStream_t)stream);
     hipLaunchKernelGGL(winograd_wgrad_kernel, dim3((unsigned)((K / WW_KB) * (C / WW_CB)), 4, (unsigned)splits), dim3(256), 0,
                        (hipStream_t)stream, p);
+    ds6g_prof_close(rec, (hipStream_t)stream);
     DS6G_LAUNCH_CHECK();
     const long n = (long)K * C;
     hipLaunchKernelGGL(winograd_wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
