@@ -46,7 +46,10 @@ struct WinoParams {
 // U[p][k][c] = (G g G^T)[p], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].  transpose_flip: build the dgrad filter
 // instead - input/output channels swapped and taps rotated by 180 degrees: g'[c][r][s][k] = g[k][2-r][2-s][c].
 __global__ __launch_bounds__(256) void winograd_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int K,
-                                                               int C, int transpose_flip) {
+                                                               int C, int transpose_flip_in) {
+    // blockIdx.y = 1 (only launched when both are wanted): the dgrad filter into the second half of u
+    const int transpose_flip = gridDim.y > 1 ? (int)blockIdx.y : transpose_flip_in;
+    if (gridDim.y > 1 && blockIdx.y == 1) u += (size_t)16 * K * C;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int Ko = transpose_flip ? C : K, Co = transpose_flip ? K : C;  // output-side (rows of U) / reduction side
     if (i >= (long)Ko * Co) return;
@@ -486,12 +489,13 @@ extern "C" {
 
 size_t ds6g_winograd_weight_floats(int K, int C) { return (size_t)16 * K * C; }
 
+// transpose_flip: 0 forward filter, 1 dgrad filter, 2 both (u then holds 2 * 16*K*C floats: forward, then dgrad)
 int ds6g_winograd_weights(const float* w, float* u, int K, int C, int transpose_flip, void* stream) {
     DS6G_ENTER();
-    DS6G_CHECK_ARG(w && u && K > 0 && C > 0);
+    DS6G_CHECK_ARG(w && u && K > 0 && C > 0 && transpose_flip >= 0 && transpose_flip <= 2);
     const long n = (long)K * C;
-    hipLaunchKernelGGL(winograd_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, u, K,
-                       C, transpose_flip);
+    hipLaunchKernelGGL(winograd_weights_kernel, dim3((unsigned)((n + 255) / 256), transpose_flip == 2 ? 2 : 1), dim3(256), 0,
+                       (hipStream_t)stream, w, u, K, C, transpose_flip);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }

@@ -218,6 +218,7 @@ class TransFuser(nn.Module):
         self._wg_map, self._wg_used, self._wg_keep = {}, {}, []
         self.overlap_wgrad_trunks = False  # measured: no gain on top of the three concurrent trunk streams
         self._fold_now = False
+        self._recording = False
         self.use_winograd = True  # 3x3 / stride-1 convs (forward and data gradient) as Winograd F(2x2, 3x3) in fp32 mode
         self.fold_bn_eval = True  # eval(): BatchNorm folded into the conv weights (no BN kernels at inference)
         self.fuse_qkv = True      # key|query|value projections as one GEMM when their parameters are contiguous (arena)
@@ -543,16 +544,22 @@ class TransFuser(nn.Module):
 
     def _conv3x3(self, x, conv, K, stride):
         """3x3 conv of a BasicBlock: Winograd F(2x2, 3x3) where the shape allows it (stride 1, exact-fp32 mode: 2.25x
-        fewer MFMA FLOPs - the direct kernel already runs at the chip's power-limited fp32 rate), else the implicit GEMM"""
+        fewer MFMA FLOPs - the direct kernel already runs at the chip's power-limited fp32 rate), else the implicit GEMM.
+        -> (y, ud): ud = the transformed dgrad filter when the backward pass will want it (recording), else None."""
         if stride == 1 and self.use_winograd and ops.winograd_ok(x.shape, K):
-            u = ops.winograd_weights(self._w(conv.weight), K, x.shape[-1], self.device)
-            return ops.conv3x3_winograd(x, u, K)
-        return ops.conv2d_fwd(x, self._w(conv.weight), K, 3, 3, stride, 1)
+            C = x.shape[-1]
+            if self._recording and ops.winograd_ok((x.shape[0], x.shape[1], x.shape[2], K), C):
+                u, ud = ops.winograd_weights(self._w(conv.weight), K, C, self.device, both=True)  # one launch for both
+                return ops.conv3x3_winograd(x, u, K), ud
+            u = ops.winograd_weights(self._w(conv.weight), K, C, self.device)
+            return ops.conv3x3_winograd(x, u, K), None
+        return ops.conv2d_fwd(x, self._w(conv.weight), K, 3, 3, stride, 1), None
 
-    def _dgrad3x3(self, dy, conv, x_shape, stride, out=None, accumulate=False):
+    def _dgrad3x3(self, dy, conv, x_shape, stride, out=None, accumulate=False, ud=None):
         K = dy.shape[-1]
         if stride == 1 and self.use_winograd and ops.winograd_ok(dy.shape, x_shape[-1]):
-            ud = ops.winograd_weights(self._w(conv.weight), K, x_shape[-1], self.device, dgrad=True)
+            if ud is None:  # (weights are unchanged between forward and backward: normally handed over by the tape)
+                ud = ops.winograd_weights(self._w(conv.weight), K, x_shape[-1], self.device, dgrad=True)
             return ops.conv3x3_winograd(dy, ud, x_shape[-1], out=out, accumulate=accumulate)
         return ops.conv2d_dgrad(dy, self._w(conv.weight), tuple(x_shape), 3, 3, stride, 1, out=out, accumulate=accumulate)
 
@@ -571,9 +578,9 @@ class TransFuser(nn.Module):
             w2, b2 = ops.bn_fold(self._w(blk.conv2.weight), blk.bn2, K, 9, K)
             out = ops.conv2d_bias_act_fwd(a1, w2.data_ptr(), b2.data_ptr(), K, 3, 3, 1, 1, relu=2, residual=idn)
             return out, None
-        c1 = self._conv3x3(x, blk.conv1, K, blk.stride)
+        c1, ud1 = self._conv3x3(x, blk.conv1, K, blk.stride)
         a1, s1 = self._bn_fwd(blk.bn1, c1, True, None, train)
-        c2 = self._conv3x3(a1, blk.conv2, K, 1)
+        c2, ud2 = self._conv3x3(a1, blk.conv2, K, 1)
         if blk.downsample is not None:
             cd = ops.conv2d_fwd(x, self._w(blk.downsample[0].weight), K, 1, 1, blk.stride, 0)
             idn, sd = self._bn_fwd(blk.downsample[1], cd, False, None, train)
@@ -589,7 +596,7 @@ class TransFuser(nn.Module):
         else:
             ops.bn_eval_prepare(bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(), C, stats[0], stats[1], bn2.eps)
         out = ops.bn_apply(c2, stats[0], stats[1], self._w(bn2.weight), self._w(bn2.bias), True, idn)
-        return out, (x, c1, a1, s1, c2, (stats[0], stats[1]), cd, sd, out)
+        return out, (x, c1, a1, s1, c2, (stats[0], stats[1]), cd, sd, out, ud1, ud2)
 
     def _gpt_block_fwd(self, blk, x, B, T, train):
         cfg = self.config
@@ -669,6 +676,7 @@ class TransFuser(nn.Module):
         cfg = self.config
         train = self.training
         self._fold_now = self.fold_bn_eval and not train and not record  # inference only: backward needs the BN tape
+        self._recording = bool(record)
         S = cfg.seq_len
         if torch.is_tensor(lidars):
             B = lidars.shape[0] // S
@@ -821,22 +829,22 @@ class TransFuser(nn.Module):
         self._wg_launch(lambda: ops.linear_wgrad(x, dy, gw, self._ws, accumulate=accumulate, dbias_ptr=gb), (x, dy))
 
     def _block_bwd(self, blk, ctx, dout, need_dx=True):
-        x, c1, a1, s1, c2, s2, cd, sd, out = ctx
+        x, c1, a1, s1, c2, s2, cd, sd, out, ud1, ud2 = ctx
         dc2, dres = self._bn_bwd(blk.bn2, dout, out, c2, s2, want_dres=True)
         self._wgrad_conv(blk.conv2, a1, dc2, 3, 1, 1)
-        da1 = self._dgrad3x3(dc2, blk.conv2, a1.shape, 1)
+        da1 = self._dgrad3x3(dc2, blk.conv2, a1.shape, 1, ud=ud2)
         dc1, _ = self._bn_bwd(blk.bn1, da1, a1, c1, s1, relu_no_residual=True)
         self._wgrad_conv(blk.conv1, x, dc1, 3, blk.stride, 1)
         if blk.downsample is not None:
             dcd, _ = self._bn_bwd(blk.downsample[1], dres, None, cd, sd)
             self._wgrad_conv(blk.downsample[0], x, dcd, 1, blk.stride, 0)
             # the 3x3 dgrad writes every input pixel; the strided 1x1 only touches the even/even parity class
-            dx = self._dgrad3x3(dc1, blk.conv1, x.shape, blk.stride)
+            dx = self._dgrad3x3(dc1, blk.conv1, x.shape, blk.stride, ud=ud1)
             ops.conv2d_dgrad(dcd, self._w(blk.downsample[0].weight), tuple(x.shape), 1, 1, blk.stride, 0, out=dx,
                              accumulate=True)
         else:
             dx = dres
-            self._dgrad3x3(dc1, blk.conv1, x.shape, blk.stride, out=dx, accumulate=True)
+            self._dgrad3x3(dc1, blk.conv1, x.shape, blk.stride, out=dx, accumulate=True, ud=ud1)
         return dx
 
     def _gpt_block_bwd(self, blk, ctx, dx2, B, T, dz2=None, next_drop=None):

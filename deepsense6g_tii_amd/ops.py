@@ -85,12 +85,13 @@ def winograd_ok(x_shape, K):
     return bool(lib().winograd_supported(N, H, W, C, K)) and lib().get_compute_mode() == 0
 
 
-def winograd_weights(w_ohwi_ptr, K, C, device, dgrad=False):
+def winograd_weights(w_ohwi_ptr, K, C, device, dgrad=False, both=False):
     """U = G g G^T of an OHWI [K, 3, 3, C] filter: [16, K, C] (forward) or, dgrad=True, [16, C, K] of the
-    channel-swapped, 180-degree-rotated filter"""
-    u = torch.empty(lib().winograd_weight_floats(K, C), dtype=F32, device=device)
-    lib().winograd_weights(w_ohwi_ptr, _p(u), K, C, int(dgrad), _stream())
-    return u
+    channel-swapped, 180-degree-rotated filter; both=True: (forward, dgrad) from one launch"""
+    n = lib().winograd_weight_floats(K, C)
+    u = torch.empty(2 * n if both else n, dtype=F32, device=device)
+    lib().winograd_weights(w_ohwi_ptr, _p(u), K, C, 2 if both else int(dgrad), _stream())
+    return (u[:n], u[n:]) if both else u
 
 
 def conv3x3_winograd(x, u, K, out=None, accumulate=False):

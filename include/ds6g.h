@@ -66,7 +66,8 @@ int ds6g_bn_fold(const float* w, const float* gamma, const float* beta, const fl
 /* ---- winograd.hip : Winograd F(2x2, 3x3) for the 3x3 / stride 1 / pad 1 convolutions of the BasicBlocks
  * (model2_seq.py:510-512,528-530,546-548,565-567): 16 GEMMs on transformed 4x4 tiles, 2.25x fewer MFMA FLOPs.
  * winograd_weights builds U[16][K][C] = G g G^T from the OHWI filter (transpose_flip = 1: the dgrad filter, i.e.
- * U[16][C][K] of the channel-swapped, 180-degree-rotated filter); conv3x3_winograd_fwd computes
+ * U[16][C][K] of the channel-swapped, 180-degree-rotated filter; 2: both in one launch, forward first, into 2x the
+ * floats), stored in MFMA fragment order; conv3x3_winograd_fwd computes
  * y[N][H][W][K] (+)= conv(x[N][H][W][C]) from it (call it with dy and the dgrad filter to obtain dx).
  * winograd_supported: H, W even, C % 16 == 0, K % 32 == 0, W/2 a multiple of 8 or a divisor of 32. */
 size_t ds6g_winograd_weight_floats(int K, int C);
