@@ -40,6 +40,9 @@ struct WinoParams {
     int col_blocks;      // TW / BTW
     unsigned x_bytes, u_bytes;
     int dbg;             // timing ablations (DS6G_WINO_DBG): 1 no patch loads, 2 no U loads, 4 no transform/store, 8 no MFMA
+    const float* bias;      // inference epilogue (BN folded into the filter): per-channel bias,
+    const float* residual;  //   identity branch [N][H][W][K],
+    int relu;               //   0 none, 1 before the residual add, 2 after it
     int accumulate;      // y += result (data gradient summed onto the gradient of the residual branch)
 };
 
@@ -267,10 +270,19 @@ __global__ __launch_bounds__(256, (TNK == 1 ? 2 : 1)) void winograd_fwd_kernel(c
                 for (int i = 0; i < 2; ++i) {
                     const float y0 = sr[i][0] + sr[i][1] + sr[i][2];
                     const float y1 = sr[i][1] - sr[i][2] - sr[i][3];
-                    float* o = p.y + (((size_t)(on * p.H + 2 * oth + i) * p.W + 2 * ocol) * p.K + k0 + j * WG_KB + kk);
+                    const size_t oi = ((size_t)(on * p.H + 2 * oth + i) * p.W + 2 * ocol) * p.K + k0 + j * WG_KB + kk;
+                    float* o = p.y + oi;
                     if (p.accumulate) {
                         o[0] += y0;
                         o[p.K] += y1;
+                    } else if (p.bias || p.residual || p.relu) {
+                        float v0 = y0, v1 = y1;
+                        if (p.bias) { const float bb = p.bias[k0 + j * WG_KB + kk]; v0 += bb; v1 += bb; }
+                        if (p.relu == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                        if (p.residual) { v0 += p.residual[oi]; v1 += p.residual[oi + p.K]; }
+                        if (p.relu == 2) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                        o[0] = v0;
+                        o[p.K] = v1;
                     } else {
                         o[0] = y0;
                         o[p.K] = y1;
@@ -512,10 +524,27 @@ int ds6g_winograd_supported(int N, int H, int W, int C, int K) {
 // y[N][H][W][K] = conv3x3 (stride 1, pad 1) of x[N][H][W][C] with the filter whose Winograd transform is u
 // (ds6g_winograd_weights; transpose_flip = 1 there turns this call into the data gradient of the same conv);
 // accumulate: y += result
+static int wino_fwd_launch(const float* x, const float* u, float* y, int N, int H, int W, int C, int K, int accumulate,
+                           const float* bias, const float* residual, int relu, void* stream);
+
 int ds6g_conv3x3_winograd_fwd(const float* x, const float* u, float* y, int N, int H, int W, int C, int K, int accumulate,
                               void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(x && u && y && ds6g_winograd_supported(N, H, W, C, K));
+    return wino_fwd_launch(x, u, y, N, H, W, C, K, accumulate, nullptr, nullptr, 0, stream);
+}
+
+// inference form (eval-mode BN folded into the filter by ds6g_bn_fold before ds6g_winograd_weights):
+// y = act(conv(x) + bias [+ residual]);  relu: 0 none, 1 before the residual add, 2 after it
+int ds6g_conv3x3_winograd_bias_act_fwd(const float* x, const float* u, const float* bias, const float* residual, float* y,
+                                       int N, int H, int W, int C, int K, int relu, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && u && y && ds6g_winograd_supported(N, H, W, C, K) && relu >= 0 && relu <= 2);
+    return wino_fwd_launch(x, u, y, N, H, W, C, K, 0, bias, residual, relu, stream);
+}
+
+static int wino_fwd_launch(const float* x, const float* u, float* y, int N, int H, int W, int C, int K, int accumulate,
+                           const float* bias, const float* residual, int relu, void* stream) {
     WinoParams p{};
     p.x = x; p.u = u; p.y = y; p.N = N; p.H = H; p.W = W; p.C = C; p.K = K;
     p.TH = H / 2; p.TW = W / 2;
@@ -526,6 +555,7 @@ int ds6g_conv3x3_winograd_fwd(const float* x, const float* u, float* y, int N, i
     p.x_bytes = (unsigned)((size_t)N * H * W * C * 4);
     p.u_bytes = (unsigned)((size_t)16 * K * C * 4);
     p.accumulate = accumulate;
+    p.bias = bias; p.residual = residual; p.relu = relu;
     { const char* e = getenv("DS6G_WINO_DBG"); p.dbg = e ? atoi(e) : 0; }
     const int row_blocks = (p.rows_total + p.BTH - 1) / p.BTH;
     // profiler variant 20000: forward / data gradient; flops = those of the direct 3x3 convolution it replaces

@@ -569,14 +569,22 @@ class TransFuser(nn.Module):
             # inference: eval-mode BN is an affine map per channel - folded into the conv weights, the block is three
             # (two) convolutions with bias / ReLU / identity epilogues and no BN pass at all
             Cin = x.shape[-1]
-            w1, b1 = ops.bn_fold(self._w(blk.conv1.weight), blk.bn1, K, 9, Cin)
-            a1 = ops.conv2d_bias_act_fwd(x, w1.data_ptr(), b1.data_ptr(), K, 3, 3, blk.stride, 1, relu=1)
+
+            def conv3(inp, conv, bn, stride, relu, residual=None):
+                C = inp.shape[-1]
+                wf, bf = ops.bn_fold(self._w(conv.weight), bn, K, 9, C)
+                if stride == 1 and self.use_winograd and ops.winograd_ok(inp.shape, K):
+                    u = ops.winograd_weights(wf.data_ptr(), K, C, self.device)
+                    return ops.conv3x3_winograd_bias_act(inp, u, bf.data_ptr(), K, relu=relu, residual=residual)
+                return ops.conv2d_bias_act_fwd(inp, wf.data_ptr(), bf.data_ptr(), K, 3, 3, stride, 1, relu=relu,
+                                               residual=residual)
+
+            a1 = conv3(x, blk.conv1, blk.bn1, blk.stride, 1)
             idn = x
             if blk.downsample is not None:
                 wd, bd = ops.bn_fold(self._w(blk.downsample[0].weight), blk.downsample[1], K, 1, Cin)
                 idn = ops.conv2d_bias_act_fwd(x, wd.data_ptr(), bd.data_ptr(), K, 1, 1, blk.stride, 0, relu=0)
-            w2, b2 = ops.bn_fold(self._w(blk.conv2.weight), blk.bn2, K, 9, K)
-            out = ops.conv2d_bias_act_fwd(a1, w2.data_ptr(), b2.data_ptr(), K, 3, 3, 1, 1, relu=2, residual=idn)
+            out = conv3(a1, blk.conv2, blk.bn2, 1, 2, residual=idn)
             return out, None
         c1, ud1 = self._conv3x3(x, blk.conv1, K, blk.stride)
         a1, s1 = self._bn_fwd(blk.bn1, c1, True, None, train)

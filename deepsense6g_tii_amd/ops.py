@@ -104,6 +104,17 @@ def conv3x3_winograd(x, u, K, out=None, accumulate=False):
     return y
 
 
+def conv3x3_winograd_bias_act(x, u, bias_ptr, K, relu=0, residual=None):
+    """inference 3x3 conv with folded BN in the Winograd domain: act(conv(x) + bias [+ residual])"""
+    N, H, W, C = x.shape
+    _chk(x)
+    y = torch.empty((N, H, W, K), dtype=F32, device=x.device)
+    if residual is not None:
+        _chk(residual, N, H, W, K)
+    lib().conv3x3_winograd_bias_act_fwd(_p(x), _p(u), bias_ptr, _p(residual), _p(y), N, H, W, C, K, int(relu), _stream())
+    return y
+
+
 def winograd_wgrad_ok(x_shape, K):
     N, H, W, C = x_shape
     return bool(lib().winograd_wgrad_supported(N, H, W, C, K)) and lib().get_compute_mode() == 0

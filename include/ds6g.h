@@ -75,6 +75,10 @@ int ds6g_winograd_weights(const float* w, float* u, int K, int C, int transpose_
 int ds6g_winograd_supported(int N, int H, int W, int C, int K);
 int ds6g_conv3x3_winograd_fwd(const float* x, const float* u, float* y, int N, int H, int W, int C, int K, int accumulate,
                               void* stream);
+/* inference form: eval-mode BN folded into the filter (ds6g_bn_fold, then ds6g_winograd_weights), epilogue fused into the
+ * output transform: y = act(conv(x) + bias [+ residual]); relu 0 none / 1 before / 2 after the residual add. */
+int ds6g_conv3x3_winograd_bias_act_fwd(const float* x, const float* u, const float* bias, const float* residual, float* y,
+                                       int N, int H, int W, int C, int K, int relu, void* stream);
 /* weight gradient of the same convs in the Winograd domain (dU = sum_tiles (A dY A^T) (B^T d B), dW = G^T dU G): 4 MFMA
  * FLOPs per pixel / channel pair / filter instead of 9.  ws: scratch for the per-split dU slabs (>= 16*K*C floats; more
  * allows more splits).  Supported: H, W even, C and K multiples of 64. */

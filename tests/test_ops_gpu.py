@@ -565,6 +565,34 @@ def test_winograd_conv3x3(dev, N, H, W, C, K):
     close((dx - base).cpu().permute(0, 3, 1, 2), x.grad, 2e-5, 2e-5)
 
 
+@pytest.mark.parametrize("relu,with_res", [(0, False), (1, False), (2, True), (1, True), (0, True)])
+def test_winograd_bias_act(dev, relu, with_res):
+    """inference epilogue of the Winograd forward: act(conv + bias [+ residual]) with the ReLU before (1) or after (2)
+    the residual add, against torch."""
+    ops = _ops()
+    N, H, W, C, K = 3, 10, 16, 64, 96
+    assert ops.winograd_ok((N, H, W, C), K)
+    g = torch.Generator().manual_seed(7 + relu)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    b = torch.randn(K, generator=g)
+    r = torch.randn(N, K, H, W, generator=g) if with_res else None
+    y = F.conv2d(x, w, b, 1, 1)
+    if relu == 1:
+        y = y.relu()
+    if r is not None:
+        y = y + r
+    if relu == 2:
+        y = y.relu()
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wg = w.permute(0, 2, 3, 1).contiguous().cuda()
+    bg = b.cuda()
+    rg = r.permute(0, 2, 3, 1).contiguous().cuda() if with_res else None
+    u = ops.winograd_weights(wg.data_ptr(), K, C, dev)
+    yg = ops.conv3x3_winograd_bias_act(xg, u, bg.data_ptr(), K, relu=relu, residual=rg)
+    close(yg.cpu().permute(0, 3, 1, 2), y, 2e-5, 2e-5)
+
+
 @pytest.mark.parametrize("N,H,W,C,K", [(2, 8, 16, 64, 64), (3, 16, 16, 128, 64), (5, 6, 10, 64, 192)])
 def test_winograd_wgrad3x3(dev, N, H, W, C, K):
     """Winograd-domain weight gradient (dU = sum_tiles E V, dW = G^T dU G, split over the tile range) against torch,
