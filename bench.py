@@ -116,14 +116,17 @@ def main():
     ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (sequences)")
     ap.add_argument("--ema", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+    ap.add_argument("--no-alt-modes", action="store_true", help="skip the extra f32x3 timing beside the exact-fp32 value")
+    ap.add_argument("--dtype", choices=("f32", "bf16", "f32x3", "f32x6"), default="f32",
                     help="matrix-core mode: f32 = exact fp32 MFMA (parity path, default); bf16 = operands rounded to bf16, "
-                         "fp32 accumulate/storage (BASELINE configs[1]-style throughput configuration)")
+                         "fp32 accumulate/storage (BASELINE configs[1]-style throughput configuration); f32x3 = split bf16 "
+                         "(hi*hi + hi*lo + lo*hi, ~2^-16 relative product error, fp32 accumulate/storage)")
     ap.add_argument("--image-only", action="store_true",
                     help="BASELINE configs[1]: zeroed LiDAR / radar inputs - the reference's own 'zerolike' missing-modality "
                          "semantics (mambafuser_seq.py:384-391); same kernels and FLOPs, other input statistics")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the three trunks on one stream (per-kernel profiling: durations are not overlapped)")
+    ap.add_argument("--debug-flags", type=lambda v: int(v, 0), default=0, help="ds6g_set_debug_flags (tuning experiments)")
     ap.add_argument("--cpu-batch", type=int, default=12)
     ap.add_argument("--cpu-steps", type=int, default=2)
     args = ap.parse_args()
@@ -135,7 +138,11 @@ def main():
     from deepsense6g_tii_amd.train import EMA, FusedAdamW, train_iteration
 
     ops.set_compute_mode(args.dtype)
-    peak_tflops = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
+    if args.debug_flags:
+        from deepsense6g_tii_amd._lib import lib
+        lib().set_debug_flags(args.debug_flags)
+    # f32x3 executes three bf16 MFMA flops per algorithmic flop: its ceiling in algorithmic flops is a third of the bf16 peak
+    peak_tflops = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32x3": PEAK_BF16_MFMA_TFLOPS / 3, "f32x6": PEAK_BF16_MFMA_TFLOPS / 6}[args.dtype]
     rank, world, local = ddist.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
@@ -210,12 +217,13 @@ def main():
         if v >= 20000:  # winograd.hip (flops recorded = those of the direct 3x3 conv it replaces)
             return ("winograd_fwd_kernel<1>", "winograd_wgrad_kernel")[v - 20000] if not short else \
                 ("winograd/fwd+dgrad", "winograd/wgrad")[v - 20000]
+        bfm = ("f32", "bf16", "f32x3", "f32x6").index(args.dtype)
         wide, epi, walk, mode, tile = v // 10000, v % 10000 // 1000, v % 1000 // 100, v % 100 // 10, v % 10
         bm, bn = VARIANT_NAMES[tile].split("x")
         if short:
             return (f"{MODE_NAMES[mode]}/{bm}x{bn}" + ("/k32" if wide else "") + ("/epi" if epi else "") +
                     ("" if walk else "/general-walk"))
-        return f"igemm_kernel<{mode}, {bm}, {bn}, {epi}, {32 if wide else 16}, {1 if args.dtype == 'bf16' else 0}, {walk}>"
+        return f"igemm_kernel<{mode}, {bm}, {bn}, {epi}, {32 if wide else 16}, {bfm}, {walk}>"
 
     if agg:
         # the roofline kernel is the matrix-core kernel with the largest share of step time.  `achieved` follows the
@@ -244,6 +252,36 @@ def main():
                                     by_variant={vname(v, short=True): dict(launches=a[0], ms=round(a[2], 3),
                                                                            tflops=round(a[1] / (a[2] * 1e-3) / 1e12, 2))
                                                 for v, a in sorted(agg.items())})
+
+    # ---- the split-bf16 matrix-core mode next to the exact one (same model / batch / timing protocol; reported beside
+    # `value`, never as it): a*b = hi*hi + hi*lo + lo*hi on the bf16 matrix cores, ~2^-16 relative product error ----
+    alt = None
+    if args.dtype == "f32" and not args.no_alt_modes:
+        with torch.no_grad():
+            model.eval()
+            ref_logits = model(fronts, lidars, radars, gps).float().clone()
+            ops.set_compute_mode("f32x3")
+            x3_logits = model(fronts, lidars, radars, gps).float()
+            dev_rel = float((x3_logits - ref_logits).abs().max() / ref_logits.abs().max())
+            model.train()
+        for _ in range(2):
+            train_iteration(model, opt, batch, ema, reducer)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            train_iteration(model, opt, batch, ema, reducer)
+        sync()
+        el3 = time.perf_counter() - t0
+        ops.set_compute_mode("f32")
+        if world > 1:
+            t = torch.tensor([el3], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el3 = float(t.item())
+        alt = {"f32x3": {"value": args.batch * world * args.steps / el3, "unit": "samples/s",
+                         "ms_per_step": el3 / args.steps * 1e3,
+                         "eval_logits_max_dev_vs_f32_rel": dev_rel,
+                         "what": "split-bf16 products (hi*hi + hi*lo + lo*hi), fp32 accumulate and storage; "
+                                 "ds6g_set_compute_mode(2); Winograd off (direct implicit GEMM); tests/test_bf16_gpu.py"}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -276,6 +314,7 @@ def main():
             "model_tflops": value * 559.3e9 / 1e12,
             "roofline": roof,
             "cpu_baseline": cpu,
+            "other_modes": alt,
         }
         if cpu:
             out["gpu_over_cpu"] = value / cpu["value"]

@@ -135,6 +135,24 @@ __device__ __forceinline__ void mma_rows(f32x16& acc, unsigned tile, const float
         for (int c = 0; c < HD / 16; ++c) {
             const f32x4 v0 = row_read<HD>(tile, l31, half * NCH + 2 * c), v1 = row_read<HD>(tile, l31, half * NCH + 2 * c + 1);
             bf16x8 a8, b8;
+            if (BF == 3) {
+                const float av[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                bf16x8 am, al, bm, bl;
+                split3_bf16x8(av, a8, am, al);
+                split3_bf16x8(breg + 8 * c, b8, bm, bl);
+                acc = mfma_x6(a8, am, al, b8, bm, bl, acc);
+                continue;
+            }
+            if (BF == 2) {  // split bf16: hi*hi + hi*lo + lo*hi (common.h)
+                const float av[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                bf16x8 al, bl;
+                split_bf16x8(av, a8, al);
+                split_bf16x8(breg + 8 * c, b8, bl);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b8, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc, 0, 0, 0);
+                continue;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 a8[e] = (__bf16)v0[e];
@@ -163,14 +181,40 @@ __device__ __forceinline__ void mma_dims(f32x16* acc, unsigned tile, const f32x1
     if (BF) {  // accumulator registers 8s..8s+7 are exactly the bf16 operand fragment of k-step s (key order krow16)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 b8;
+            bf16x8 b8, bl, bm;
+            if (BF >= 2) {
+                float pv[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) b8[e] = (__bf16)p[8 * s2 + e];
+                for (int e = 0; e < 8; ++e) pv[e] = p[8 * s2 + e];
+                if (BF == 3) split3_bf16x8(pv, b8, bm, bl); else split_bf16x8(pv, b8, bl);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b8[e] = (__bf16)p[8 * s2 + e];
+            }
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk) {
                 bf16x8 a8;
+                if (BF == 3) {
+                    float av[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a8[e] = (__bf16)dim_read<HD>(tile, dtab, 8 * s2 + e, blk);
+                    for (int e = 0; e < 8; ++e) av[e] = dim_read<HD>(tile, dtab, 8 * s2 + e, blk);
+                    bf16x8 am, al;
+                    split3_bf16x8(av, a8, am, al);
+                    acc[blk] = mfma_x6(a8, am, al, b8, bm, bl, acc[blk]);
+                    continue;
+                }
+                if (BF == 2) {
+                    float av[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) av[e] = dim_read<HD>(tile, dtab, 8 * s2 + e, blk);
+                    bf16x8 al;
+                    split_bf16x8(av, a8, al);
+                    acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b8, acc[blk], 0, 0, 0);
+                    acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, bl, acc[blk], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a8[e] = (__bf16)dim_read<HD>(tile, dtab, 8 * s2 + e, blk);
+                }
                 acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[blk], 0, 0, 0);
             }
         }
@@ -595,6 +639,8 @@ int launch_hd_bf(const AttnParams& p, int hd, dim3 grid, hipStream_t st) {
 
 template <int KIND>
 int launch_hd(const AttnParams& p, int hd, dim3 grid, hipStream_t st) {
+    if (g_ds6g_bf16 == 3) return launch_hd_bf<KIND, 3>(p, hd, grid, st);
+    if (g_ds6g_bf16 == 2) return launch_hd_bf<KIND, 2>(p, hd, grid, st);
     return g_ds6g_bf16 ? launch_hd_bf<KIND, 1>(p, hd, grid, st) : launch_hd_bf<KIND, 0>(p, hd, grid, st);
 }
 

@@ -38,8 +38,43 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #endif
 
-// process-wide matrix-core mode (ds6g_set_compute_mode): 0 = exact fp32 MFMA, 1 = bf16 operands / fp32 accumulate
+// process-wide matrix-core mode (ds6g_set_compute_mode): 0 = exact fp32 MFMA, 1 = bf16 operands / fp32 accumulate,
+// 2 = split bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate), 3 = three-way split bf16 (six products, fp32-grade)
 extern int g_ds6g_bf16;
+
+#ifdef __HIPCC__
+// a ~= hi + lo with hi = bf16(a) (RNE), lo = bf16(a - hi): |a - hi - lo| <= 2^-16 |a|
+__device__ __forceinline__ void split_bf16x8(const float* f, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)f[e];
+        hi[e] = h;
+        lo[e] = (__bf16)(f[e] - (float)h);
+    }
+}
+// a ~= hi + mid + lo (three bf16 pieces, 24 significand bits): |a - hi - mid - lo| <= 2^-24 |a|
+__device__ __forceinline__ void split3_bf16x8(const float* f, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)f[e];
+        const float r1 = f[e] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        hi[e] = h;
+        mid[e] = m;
+        lo[e] = (__bf16)(r1 - (float)m);
+    }
+}
+// acc += a * b with both operands split three ways: the six products above 2^-24 relative, smallest first
+__device__ __forceinline__ f32x16 mfma_x6(const bf16x8& ah, const bf16x8& am, const bf16x8& al, const bf16x8& bh,
+                                          const bf16x8& bm, const bf16x8& bl, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+#endif
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -77,6 +77,11 @@ struct IgemmParams {
 // BF 1: operands are rounded to bf16 (RNE) on the way from the LDS fragment to the matrix core and one
 // v_mfma_f32_32x32x16_bf16 replaces the eight fp32 MFMAs of a k-tile (fp32 accumulate, fp32 storage everywhere):
 // the "bf16 forward/backward" throughput configuration of BASELINE.json; BF 0 is the exact-fp32 parity path.
+// BF 2: split-bf16 ("bf16x3"): every fp32 operand is split into hi = bf16(a), lo = bf16(a - hi) and the product is
+// hi*hi + hi*lo + lo*hi on the bf16 matrix cores (fp32 accumulate): relative product error <= ~2^-16 - between fp32
+// and TF32 - for 3/16 of the exact path's matrix-core cycles.
+// BF 3: three-way split (hi, mid, lo = 24 significand bits), the six products above 2^-24: fp32-grade results
+// for 6/16 of the exact path's matrix-core cycles.
 // FAST 1: the k walk is wave-uniform - a k-tile never straddles a filter tap (FWD: C % BK == 0, DGRAD: K % BK == 0) or
 // an image row group (WGRAD: see wgrad_fast_ok) - so the per-lane byte offsets are constants of the current tap / of
 // the lane, and the per-k-tile advance lives in SGPRs and rides in the buffer instruction's scalar offset: the loop
@@ -508,15 +513,48 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams pin) {
             static_assert(!BF || BK % 16 == 0, "bf16 k-tiles are multiples of 16");
 #pragma unroll
             for (int q = 0; q < BK / 16; ++q) {
-                bf16x8 a8[TM], b8[TN];
+                if (BF == 3) {
+                    bf16x8 ah[TM], am[TM], al3[TM], bh[TN], bm[TN], bl3[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i) split3_bf16x8(&af[i][8 * q], ah[i], am[i], al3[i]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) a8[i][e] = (__bf16)af[i][8 * q + e];
+                    for (int j = 0; j < TN; ++j) split3_bf16x8(&bf[j][8 * q], bh[j], bm[j], bl3[j]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) b8[j][e] = (__bf16)bf[j][8 * q + e];
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = mfma_x6(ah[i], am[i], al3[i], bh[j], bm[j], bl3[j], acc[i][j]);
+                    continue;
+                }
+                bf16x8 a8[TM], b8[TN], al[TM], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if (BF == 2) split_bf16x8(&af[i][8 * q], a8[i], al[i]);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a8[i][e] = (__bf16)af[i][8 * q + e];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (BF == 2) split_bf16x8(&bf[j][8 * q], b8[j], bl[j]);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) b8[j][e] = (__bf16)bf[j][8 * q + e];
+                    }
+                }
+                if (BF == 2) {  // the two cross terms first (small), the leading term last
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], b8[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], bl[j], acc[i][j], 0, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -755,18 +793,24 @@ int launch_igemm(IgemmParams& p, int splits, int tile, hipStream_t st) {
         (void)hipEventCreate(&rec->e1);
         (void)hipEventRecord(rec->e0, st);
     }
+    const int bfm = g_ds6g_bf16;
+#define DS6G_TILE(EPI_, BK_, FAST_)                                               \
+    do {                                                                          \
+        if (bfm == 3) launch_tile<MODE, EPI_, BK_, 3, FAST_>(p, splits, tile, st); \
+        else if (bfm == 2) launch_tile<MODE, EPI_, BK_, 2, FAST_>(p, splits, tile, st); \
+        else if (bfm == 1) launch_tile<MODE, EPI_, BK_, 1, FAST_>(p, splits, tile, st); \
+        else launch_tile<MODE, EPI_, BK_, 0, FAST_>(p, splits, tile, st);         \
+    } while (0)
     if (bk32) {
         if constexpr (MODE != MODE_WGRAD) {
-            if (g_ds6g_bf16) { if (epi) launch_tile<MODE, 1, 32, 1, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 32, 1, 1>(p, splits, tile, st); }
-            else             { if (epi) launch_tile<MODE, 1, 32, 0, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 32, 0, 1>(p, splits, tile, st); }
+            if (epi) DS6G_TILE(1, 32, 1); else DS6G_TILE(0, 32, 1);
         }
-    } else if (g_ds6g_bf16) {
-        if (fast) { if (epi) launch_tile<MODE, 1, 16, 1, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 1, 1>(p, splits, tile, st); }
-        else      { if (epi) launch_tile<MODE, 1, 16, 1, 0>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 1, 0>(p, splits, tile, st); }
+    } else if (fast) {
+        if (epi) DS6G_TILE(1, 16, 1); else DS6G_TILE(0, 16, 1);
     } else {
-        if (fast) { if (epi) launch_tile<MODE, 1, 16, 0, 1>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 0, 1>(p, splits, tile, st); }
-        else      { if (epi) launch_tile<MODE, 1, 16, 0, 0>(p, splits, tile, st); else launch_tile<MODE, 0, 16, 0, 0>(p, splits, tile, st); }
+        if (epi) DS6G_TILE(1, 16, 0); else DS6G_TILE(0, 16, 0);
     }
+#undef DS6G_TILE
     if (rec) (void)hipEventRecord(rec->e1, st);
     g_last_variant = variant;
     DS6G_LAUNCH_CHECK();

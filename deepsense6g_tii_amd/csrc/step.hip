@@ -208,8 +208,9 @@ int ds6g_small_linear_bwd(const float* dy, const float* y_mask, const float* x, 
 
 int ds6g_version(void) { return 1; }
 
-int ds6g_set_compute_mode(int bf16_matrix_cores) {
-    g_ds6g_bf16 = bf16_matrix_cores ? 1 : 0;
+int ds6g_set_compute_mode(int mode) {
+    if (mode < 0 || mode > 3) return DS6G_ERR_ARG;
+    g_ds6g_bf16 = mode;
     return 0;
 }
 int ds6g_get_compute_mode(void) { return g_ds6g_bf16; }

@@ -306,15 +306,20 @@ def axpby(a, b, alpha=1.0, beta=1.0, out=None):
     return o
 
 
+_MODES = {"f32": 0, "bf16": 1, "f32x3": 2, "f32x6": 3}
+
+
 def set_compute_mode(mode: str):
     """Process-wide matrix-core mode of the GEMM-shaped kernels (ds6g_set_compute_mode):
-    "f32"  - exact fp32 MFMA, the parity path (default);
-    "bf16" - operands rounded to bf16 on the way into the MFMA, fp32 accumulate and storage (throughput mode; the
-             reference has no mixed precision, tolerances for it are declared in tests/test_bf16_gpu.py)."""
-    if mode not in ("f32", "bf16"):
-        raise ValueError(f"compute mode must be 'f32' or 'bf16', got {mode!r}")
-    lib().set_compute_mode(1 if mode == "bf16" else 0)
+    "f32"   - exact fp32 MFMA, the parity path (default);
+    "bf16"  - operands rounded to bf16 on the way into the MFMA, fp32 accumulate and storage (throughput mode; the
+              reference has no mixed precision, tolerances for it are declared in tests/test_bf16_gpu.py);
+    "f32x3" - split bf16: a*b = hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate and storage; relative
+              product error <= ~2^-16 (tests/test_bf16_gpu.py holds it to the 1e-3 bar of the exact path)."""
+    if mode not in _MODES:
+        raise ValueError(f"compute mode must be one of {sorted(_MODES)}, got {mode!r}")
+    lib().set_compute_mode(_MODES[mode])
 
 
 def get_compute_mode() -> str:
-    return "bf16" if lib().get_compute_mode() == 1 else "f32"
+    return {v: k for k, v in _MODES.items()}[lib().get_compute_mode()]

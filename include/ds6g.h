@@ -39,8 +39,11 @@ int ds6g_profile_end(int* variants, double* flops, float* ms, int cap);
 int ds6g_set_debug_flags(int flags);
 /* matrix-core mode of the conv / linear / attention kernels (process-wide): 0 (default) = exact fp32 MFMA, the parity
  * path; 1 = operands rounded to bf16 on the way into the matrix cores, fp32 accumulate, fp32 storage (throughput
- * configuration "bf16 forward/backward" of BASELINE.json).  Everything else (BN, LN, softmax, loss, AdamW) stays fp32. */
-int ds6g_set_compute_mode(int bf16_matrix_cores);
+ * configuration "bf16 forward/backward" of BASELINE.json); 2 = split bf16 ("bf16x3"): each fp32 operand a is split into
+ * hi = bf16(a), lo = bf16(a - hi) and a*b is evaluated as hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32
+ * accumulation - relative product error <= ~2^-16 (between fp32 and TF32), fp32 storage.  Everything else (BN, LN, softmax,
+ * loss, AdamW) stays fp32.  Returns DS6G_ERR_ARG for any other mode. */
+int ds6g_set_compute_mode(int mode);
 int ds6g_get_compute_mode(void);
 
 /* ---- igemm.hip : Conv2d / Linear as implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------
