@@ -20,6 +20,7 @@
 #include "common.h"
 
 int g_ds6g_attn_percu = 0;
+int g_ds6g_attn_handover = 1;  // 0: backward recomputes S / dP in every kernel (ds6g_set_debug_flags 0x01000000)
 
 namespace {
 
@@ -48,6 +49,11 @@ struct AttnParams {
     float dscale;
     uint64_t seed;
     uint64_t seed_off;
+    // backward hand-over (see attn_bwd_dkv_kernel): 32 x 32 tiles of dS / dropped P in the dK/dV kernel's accumulator
+    // order, [b*nh + h][query tile < nkg][key group < nkg][reg / 4][lane 64][reg % 4]
+    float* hs;
+    float* hp;
+    int nkg;
 };
 
 __device__ __forceinline__ int krow16(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -257,11 +263,13 @@ __device__ __forceinline__ void store_rows(const f32x16* acc, float* base, int l
 }
 
 #define ATTN_COMMON()                                                                                  \
-    constexpr int NB = (HD + 31) / 32;                                                                 \
     __shared__ __attribute__((aligned(16))) float Xa0[32 * HD];                                        \
     __shared__ __attribute__((aligned(16))) float Xa1[32 * HD];                                        \
     __shared__ __attribute__((aligned(16))) float Xb0[32 * HD];                                        \
     __shared__ __attribute__((aligned(16))) float Xb1[32 * HD];                                        \
+    ATTN_GEOM()
+#define ATTN_GEOM()                                                                                    \
+    constexpr int NB = (HD + 31) / 32;                                                                 \
     const int tid = threadIdx.x, lane = tid & 63;                                                      \
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                         \
     const int l31 = lane & 31, half = lane >> 5;                                                       \
@@ -281,7 +289,7 @@ __device__ __forceinline__ void store_rows(const f32x16* acc, float* base, int l
     const int h = by_ % p.nh, split = by_ / p.nh, b = bz_;                                             \
     const int T = p.T;                                                                                 \
     const long head_off = (long)b * T * p.ld + h * HD;                                                 \
-    const long head_offq = (long)b * T * p.ldq + h * HD;                                               \
+    [[maybe_unused]] const long head_offq = (long)b * T * p.ldq + h * HD;                                            \
     [[maybe_unused]] const long head_offd = (long)b * T * p.ldd + h * HD;                              \
     const int ntiles = (T + 31) / 32;                                                                  \
     const int t_begin = split * p.tiles_per_split;                                                     \
@@ -485,7 +493,12 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
 // dK, dV: one wave = 32 keys (key on the lane), loop over (a split of) the query tiles.
 // PART 0 = both (4 products per tile); 1 = dV only (S, dV); 2 = dK only (S, dP, dK).  At HD = 128 the fused form
 // needs > 512 registers (K, V fragments + two accumulator sets), so it runs as PART 1 + PART 2.
-template <int HD, int PART, int BF>
+// HAND 1: the kernel also writes its dS tiles (and, PART 2, the dropped probabilities) to HBM in accumulator order -
+// 16 fully coalesced 256-B stores per wave and tile.  attn_bwd_dq2_kernel then forms dQ = dS K from them (one product
+// instead of the three of attn_bwd_dq_kernel, after a 32 x 32 transpose through LDS: the two kernels hold the score tile
+// in opposite orientations), and at HD = 128 attn_bwd_dv2_kernel forms dV = P^T dO without recomputing S: the whole
+// backward is the minimal 5 products instead of 7 (8 at HD = 128).
+template <int HD, int PART, int BF, int HAND = 0>
 __global__ __launch_bounds__(256, (HD <= 32 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2 : 1)))) void attn_bwd_dkv_kernel(const AttnParams p) {
     constexpr bool DO_DV = PART != 2, DO_DK = PART != 1;
     ATTN_COMMON();
@@ -546,12 +559,28 @@ __global__ __launch_bounds__(256, (HD <= 32 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
             }
             s[r] = pr;  // dropped probabilities
         }
+        if (HAND) {  // tile image: [reg / 4][lane][reg % 4] - four 1-KiB stores per wave and tensor
+            const size_t tile = ((((size_t)(b * p.nh + h) * p.nkg + qt) * p.nkg) + (bx_ * 4 + wave)) * 1024 + lane * 4;
+            f32x4* ds_out = reinterpret_cast<f32x4*>(p.hs + tile);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                ds_out[g * 64] = key_ok ? f32x4{dp[4 * g], dp[4 * g + 1], dp[4 * g + 2], dp[4 * g + 3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (PART == 2) {
+                f32x4* p_out = reinterpret_cast<f32x4*>(p.hp + tile);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    p_out[g * 64] = key_ok ? f32x4{s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);  // phase fences keep the LDS-read prefetch of one product from
         if (DO_DV) mma_dims<HD, BF>(dv, Oc, s, dtab);  // overlapping the live registers of the next
         __builtin_amdgcn_sched_barrier(0);
         if (DO_DK) mma_dims<HD, BF>(dk, Qc, dp, dtab);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the next tile's DMA is older than this step's hand-over stores and vmcnt retires in order: wait for the DMA
+        // only, the 4 (8) stores drain under the next step
+        if (HAND) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PART == 2 ? 8 : 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
 
@@ -573,6 +602,138 @@ __global__ __launch_bounds__(256, (HD <= 32 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
         if (DO_DK) store_rows<HD>(dk, p.dk + (size_t)split * p.slab + head_off, p.ld, key, T, half, 1.0f);
         if (DO_DV) store_rows<HD>(dv, p.dv + (size_t)split * p.slab + head_off, p.ld, key, T, half, 1.0f);
     }
+}
+
+// delta[b][h][t] = sum_d dO[t][h*hd + d] * O[t][h*hd + d]  (hand-over path: the dK/dV kernel runs first and needs it)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o,
+                                                         float* __restrict__ delta, int B, int T, int nh, int hd, int ld) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * T * nh) return;
+    const int h = (int)(i % nh);
+    const long row = i / nh;
+    const float* a = o + row * ld + h * hd;
+    const float* g = d_o + row * ld + h * hd;
+    float acc = 0.f;
+    for (int d = 0; d < hd; d += 4) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(a + d), y = *reinterpret_cast<const f32x4*>(g + d);
+        acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    }
+    const int b = (int)(row / T), t = (int)(row % T);
+    delta[((long)b * nh + h) * T + t] = acc;
+}
+
+// dQ from the dS tiles of attn_bwd_dkv_kernel<.., HAND = 1>: one wave = 32 queries (= one query tile), loop over (a split
+// of) the key tiles; the stored tile holds dS[query krow16(r, half)][key lane&31], the B operand of dQ^T += K^T dS^T
+// wants dS[query lane&31][key krow16(r, half)]: a 32 x 32 transpose through a wave-private LDS patch (row stride 33).
+template <int HD, int BF>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) float Xa0[32 * HD];
+    __shared__ __attribute__((aligned(16))) float Xa1[32 * HD];
+    __shared__ float Tr[4][32 * 33];
+    ATTN_GEOM();
+    const int q_row = bx_ * 128 + wave * 32 + l31;
+    const int qt = bx_ * 4 + wave;
+    const i32x4 k_srd = make_srd(p.k, p.bytes_q);
+    f32x16 dq[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[blk][r] = 0.f;
+    const float* tiles = p.hs + (((size_t)(b * p.nh + h) * p.nkg + qt) * p.nkg) * 1024 + lane * 4;
+    const bool have = qt < ntiles;  // wave-uniform: query tiles beyond T were never written
+    float f[16], fn[16];
+    auto fetch = [&](float* dst, int kt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = have ? *reinterpret_cast<const f32x4*>(tiles + (size_t)kt * 1024 + g * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+            dst[4 * g] = v[0]; dst[4 * g + 1] = v[1]; dst[4 * g + 2] = v[2]; dst[4 * g + 3] = v[3];
+        }
+    };
+    float* tw = Tr[wave];
+    auto step = [&](const float* Kcp, const float* Kn, int kt, bool more) {
+        if (more) {
+            tile_dma<HD>(k_srd, Kn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
+            fetch(fn, kt + 1);
+        }
+        const unsigned Kc = opaque_tile(Kcp);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tw[krow16(r, half) * 33 + l31] = f[r];
+        __builtin_amdgcn_wave_barrier();
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = tw[l31 * 33 + krow16(r, half)];
+        __builtin_amdgcn_wave_barrier();
+        mma_dims<HD, BF>(dq, Kc, s, dtab);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) f[r] = fn[r];
+        }
+    };
+    if (t_begin < t_end) {
+        tile_dma<HD>(k_srd, Xa0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
+        fetch(f, t_begin);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = t_begin; kt < t_end; kt += 2) {
+        step(Xa0, Xa1, kt, kt + 1 < t_end);
+        if (kt + 1 < t_end) step(Xa1, Xa0, kt + 1, kt + 2 < t_end);
+    }
+    if (p.splits == 1) store_rows<HD>(dq, p.dq + head_offd, p.ldd, q_row, T, half, 1.0f);
+    else store_rows<HD>(dq, p.dq + (size_t)split * p.slab + head_off, p.ld, q_row, T, half, 1.0f);
+}
+
+// dV from the dropped-probability tiles of attn_bwd_dkv_kernel<HD, 2, .., HAND = 1> (HD = 128, where the fused dK/dV form
+// does not fit the register file): same orientation as the producer, the tile is the B operand as stored.
+template <int HD, int BF>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dv2_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) float Xb0[32 * HD];
+    __shared__ __attribute__((aligned(16))) float Xb1[32 * HD];
+    ATTN_GEOM();
+    const int key = bx_ * 128 + wave * 32 + l31;
+    const i32x4 do_srd = make_srd(p.d_o, p.bytes);
+    f32x16 dv[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dv[blk][r] = 0.f;
+    const float* tiles = p.hp + ((size_t)(b * p.nh + h) * p.nkg * p.nkg + (bx_ * 4 + wave)) * 1024 + lane * 4;
+    const size_t qstride = (size_t)p.nkg * 1024;
+    f32x16 s, sn;
+    auto fetch = [&](f32x16& dst, int qt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tiles + (size_t)qt * qstride + g * 256);
+            dst[4 * g] = v[0]; dst[4 * g + 1] = v[1]; dst[4 * g + 2] = v[2]; dst[4 * g + 3] = v[3];
+        }
+    };
+    auto step = [&](const float* Ocp, const float* On, int qt, bool more) {
+        if (more) {
+            tile_dma<HD>(do_srd, On, (unsigned)head_off, (qt + 1) * 32, T, p.ld, wave, lane);
+            fetch(sn, qt + 1);
+        }
+        const unsigned Oc = opaque_tile(Ocp);
+        mma_dims<HD, BF>(dv, Oc, s, dtab);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (more) s = sn;
+    };
+    if (t_begin < t_end) {
+        tile_dma<HD>(do_srd, Xb0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
+        fetch(s, t_begin);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int qt = t_begin; qt < t_end; qt += 2) {
+        step(Xb0, Xb1, qt, qt + 1 < t_end);
+        if (qt + 1 < t_end) step(Xb1, Xb0, qt + 1, qt + 2 < t_end);
+    }
+    if (p.splits == 1) store_rows<HD>(dv, p.dv + head_offd, p.ldd, key, T, half, 1.0f);
+    else store_rows<HD>(dv, p.dv + (size_t)split * p.slab + head_off, p.ld, key, T, half, 1.0f);
 }
 
 // out[row][0..cols) = sum_s part[s][row][0..cols)   (dq / dk / dv split slabs; rows of stride ld_in -> ld_out).
@@ -622,6 +783,12 @@ int launch_hd_bf(const AttnParams& p, int hd, dim3 grid, hipStream_t st) {
                 hipLaunchKernelGGL((attn_bwd_dkv_kernel<(HDV >= 128 ? 64 : HDV), 0, BF>), grid, dim3(256), 0, st, p); \
             }                                                                                                 \
         }                                                                                                     \
+        if (KIND == 3) {                                                                                      \
+            if (HDV >= 128) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 2, BF, 1>), grid, dim3(256), 0, st, p); \
+            else hipLaunchKernelGGL((attn_bwd_dkv_kernel<(HDV >= 128 ? 64 : HDV), 0, BF, 1>), grid, dim3(256), 0, st, p); \
+        }                                                                                                     \
+        if (KIND == 4) hipLaunchKernelGGL((attn_bwd_dv2_kernel<(HDV >= 128 ? HDV : 128), BF>), grid, dim3(256), 0, st, p); \
+        if (KIND == 5) hipLaunchKernelGGL((attn_bwd_dq2_kernel<HDV, BF>), grid, dim3(256), 0, st, p);         \
         break;
     switch (hd) {
         ATTN_CASE(16)
@@ -649,9 +816,15 @@ int launch_hd(const AttnParams& p, int hd, dim3 grid, hipStream_t st) {
 extern "C" {
 
 // scratch that lets the split paths use up to 8 splits (forward: partial outputs + (m,l); backward: dk + dv slabs)
+static size_t handover_bytes(int B, int T, int nh, int hd) {
+    const size_t nkg = (size_t)cdiv(T, 128) * 4;
+    return (size_t)B * nh * nkg * nkg * 1024 * sizeof(float) * (hd >= 128 ? 2 : 1);
+}
+// ... plus, for the backward, the dS (and at hd = 128 the dropped-P) tiles handed from the dK/dV kernel to the dQ / dV
+// kernels; with less than this the backward falls back to recomputing the scores in every kernel
 size_t ds6g_attention_workspace_bytes(int B, int T, int nh, int hd, int ld) {
     const size_t slab = (size_t)B * T * ld * sizeof(float);
-    return 2 * 8 * slab + (size_t)8 * B * nh * T * 2 * sizeof(float);
+    return 2 * 8 * slab + (size_t)8 * B * nh * T * 2 * sizeof(float) + handover_bytes(B, T, nh, hd);
 }
 
 // o = dropout(softmax(q k^T / sqrt(hd))) v ; lse[b][h][t] = logsumexp of the scaled scores
@@ -715,6 +888,57 @@ int ds6g_attention_bwd(const float* q, const float* k, const float* v, const flo
     const int blocks128 = cdiv(T, 128);
     const int cols4 = nh * hd / 4;
     const long n4 = (long)B * T * cols4;
+    const size_t hand = handover_bytes(B, T, nh, hd);
+    if (g_ds6g_attn_handover && ws && ws_bytes >= hand + 2 * slab * sizeof(float)) {
+        // ---- hand-over path: delta -> dK(/dV) kernel that also writes its dS (and P) tiles -> [dV from P] -> dQ from dS
+        p.hs = (float*)ws;
+        p.hp = hd >= 128 ? p.hs + hand / sizeof(float) / 2 : nullptr;
+        p.nkg = blocks128 * 4;
+        float* wsf = (float*)((char*)ws + hand);
+        const size_t wsb = ws_bytes - hand;
+        hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((long)B * T * nh, 256)), dim3(256), 0, st, o, d_o, delta, B, T, nh,
+                           hd, ld);
+        DS6G_LAUNCH_CHECK();
+        auto plan = [&](int per_cu, size_t slabs_per_split) {
+            const size_t cap = wsb / (slabs_per_split * slab * sizeof(float));
+            int splits = pick_splits((long)blocks128 * nh * B, ntiles, per_cu, (int)(cap < 8 ? cap : 8));
+            if (splits < 1) splits = 1;
+            p.tiles_per_split = cdiv(ntiles, splits);
+            p.splits = cdiv(ntiles, p.tiles_per_split);
+        };
+        const bool two_pass = hd >= 128;
+        plan(hd >= 128 ? 1 : (hd >= 64 ? 2 : 3), two_pass ? 1 : 2);
+        p.dk = p.splits == 1 ? dk : wsf;
+        p.dv = p.splits == 1 ? dv : wsf + (size_t)p.splits * slab;
+        int rc = launch_hd<3>(p, hd, dim3(blocks128, nh * p.splits, B), st);
+        if (rc) return rc;
+        if (p.splits > 1) {
+            hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256), two_pass ? 1 : 2), dim3(256), 0, st, (const float*)wsf, dk,
+                               (const float*)(wsf + (size_t)p.splits * slab), dv, n4, cols4, ld, ld_dqkv, p.splits, slab);
+            DS6G_LAUNCH_CHECK();
+        }
+        if (two_pass) {
+            plan(2, 1);
+            p.dv = p.splits == 1 ? dv : wsf;
+            rc = launch_hd<4>(p, hd, dim3(blocks128, nh * p.splits, B), st);
+            if (rc) return rc;
+            if (p.splits > 1) {
+                hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256), 1), dim3(256), 0, st, (const float*)wsf, dv,
+                                   (const float*)nullptr, (float*)nullptr, n4, cols4, ld, ld_dqkv, p.splits, slab);
+                DS6G_LAUNCH_CHECK();
+            }
+        }
+        plan(hd >= 64 ? 2 : 3, 1);
+        p.dq = p.splits == 1 ? dq : wsf;
+        rc = launch_hd<5>(p, hd, dim3(blocks128, nh * p.splits, B), st);
+        if (rc) return rc;
+        if (p.splits > 1) {
+            hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256), 1), dim3(256), 0, st, (const float*)wsf, dq,
+                               (const float*)nullptr, (float*)nullptr, n4, cols4, ld, ld_dqkv, p.splits, slab);
+            DS6G_LAUNCH_CHECK();
+        }
+        return DS6G_OK;
+    }
     // ---- dQ (split over keys)
     {
         const size_t max_by_ws = ws ? ws_bytes / (slab * sizeof(float)) : 1;

@@ -23,6 +23,7 @@
 #include <vector>
 
 extern int g_ds6g_attn_percu;  // attention.hip: split-heuristic override (timing experiments)
+extern int g_ds6g_attn_handover;
 extern int g_wino_kb64;         // winograd.hip: 64-channel workgroups (timing experiments)
 
 // LDS stages of the k loop (DMA runs STAGES-1 k-tiles ahead).  Measured on gfx950 (tools/bench_igemm.py): fwd / dgrad
@@ -941,6 +942,7 @@ void ds6g_prof_close(void* rec, hipStream_t st) {
 extern "C" {
 int ds6g_set_debug_flags(int flags) {
     g_dbg = flags & 0xbf;  // 0x80: force the general (FAST 0) walk
+    g_ds6g_attn_handover = (flags & 0x01000000) ? 0 : 1;
     g_ds6g_attn_percu = (flags >> 20) & 0xf;  // attention: resident-workgroups-per-CU assumption of the split heuristic
     g_wino_kb64 = (flags & 0x02000000) ? 1 : 0;
     g_bf16_bk32 = (flags & 0x10000000) ? 0 : 1;

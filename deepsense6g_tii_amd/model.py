@@ -334,6 +334,16 @@ class TransFuser(nn.Module):
                 return ws
         return self._ws_main
 
+    def _attn_ws(self, B, T, nh, C):
+        """scratch for the attention backward, grown (main stream only) to what lets the dK/dV kernel hand its dS / P
+        tiles to the dQ / dV kernels instead of every kernel recomputing the scores (ds6g_attention_workspace_bytes)"""
+        ws = self._ws
+        if ws is self._ws_main:
+            need = int(lib().attention_workspace_bytes(B, T, nh, C // nh, C))
+            if need > ws.nbytes:
+                self._ws_main = ws = ops.Workspace(self.device, need)
+        return ws
+
     def _fork(self):
         """-> the three trunk streams, each ordered after everything enqueued so far on the current stream.
         Discipline that keeps the caching allocator safe without record_stream(): between _fork() and _join() the
@@ -882,12 +892,13 @@ class TransFuser(nn.Module):
         fg = self._qkv_fused(at, grads=True) if fw is not None else None
         if fg is not None:  # gradients of the fused projection: one [M, 3C] matrix, one wgrad, one dgrad
             dkqv = torch.empty((dy.shape[0], 3 * C), dtype=F32, device=dy.device)
-            ops.attention_bwd(q, k, v, y, dy, lse, B, T, nh, self._ws, pa, self._seed, off_a,
+            ops.attention_bwd(q, k, v, y, dy, lse, B, T, nh, self._attn_ws(B, T, nh, C), pa, self._seed, off_a,
                               out=(dkqv[:, C:2 * C], dkqv[:, :C], dkqv[:, 2 * C:]))
             self._linear_wgrad(h, dkqv, fg[0], bool(self._g(at.key.weight)[1]), fg[1])
             dh = ops.linear_dgrad(dkqv, fw[0], C)
         else:
-            dq, dk, dv = ops.attention_bwd(q, k, v, y, dy, lse, B, T, nh, self._ws, pa, self._seed, off_a)
+            dq, dk, dv = ops.attention_bwd(q, k, v, y, dy, lse, B, T, nh, self._attn_ws(B, T, nh, C), pa, self._seed,
+                                           off_a)
             self._lin_param_grads(at.query, h, dq)
             self._lin_param_grads(at.key, h, dk)
             self._lin_param_grads(at.value, h, dv)

@@ -131,7 +131,10 @@ int ds6g_colsum(const float* x, long M, int C, float* out, int accumulate, void*
  * att @ v, head merge).  Head h lives at columns h*hd of every operand.  q/k/v: [B*T][ld_qkv] (ld_qkv = 3C when
  * they are column blocks of ONE fused key|query|value projection output, model2_seq.py:97-99); o / d_o: [B*T][ld];
  * dq/dk/dv: [B*T][ld_dqkv] (again 3C to write one fused gradient matrix).  hd in {16,32,64,128}.
- * ws: scratch for the split-loop partial results (any size; more allows more splits, see *_workspace_bytes). */
+ * ws: scratch for the split-loop partial results (any size; more allows more splits, see *_workspace_bytes).  With the
+ * full *_workspace_bytes the backward hands its dS (and, hd = 128, dropped-P) tiles from the dK/dV kernel to the dQ / dV
+ * kernels through ws (5 matrix products); with less it recomputes the scores in every kernel (7-8 products, same results
+ * up to summation order). */
 size_t ds6g_attention_workspace_bytes(int B, int T, int nh, int hd, int ld);
 int ds6g_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int T, int nh,
                        int hd, int ld_qkv, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,

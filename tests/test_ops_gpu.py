@@ -274,6 +274,35 @@ def test_attention(dev, B, T, nh, hd):
     close(dv, v.grad, 1e-4, 2e-5)
 
 
+@pytest.mark.parametrize("hd", [16, 32, 64, 128])
+def test_attention_bwd_recompute_and_handover_agree(dev, hd):
+    """The backward has two forms: every kernel recomputes S / dP (7-8 products; taken when the workspace cannot hold
+    the 32 x 32 dS / P tiles, or with debug flag 0x01000000), and the hand-over form (dK/dV kernel writes its dS and P
+    tiles, dQ / dV are formed from them: 5 products).  Both against torch, with dropout on, and against each other."""
+    from deepsense6g_tii_amd._lib import lib
+    ops = _ops()
+    B, T, nh = 2, 333, 4   # T = 10 * 32 + 13: ragged last tile, 3 blocks of 128
+    C = nh * hd
+    g = torch.Generator().manual_seed(hd)
+    q, k, v, do = (torch.randn(B * T, C, generator=g).cuda() for _ in range(4))
+    big = ops.Workspace(dev, 256 << 20)
+    assert lib().attention_workspace_bytes(B, T, nh, hd, C) <= big.nbytes
+    small = ops.Workspace(dev, 4 * B * T * C * 4)   # room for split slabs only
+    o, lse = ops.attention_fwd(q, k, v, B, T, nh, big, drop_p=0.1, seed=11, seed_off=5)
+    hand = ops.attention_bwd(q, k, v, o, do, lse, B, T, nh, big, drop_p=0.1, seed=11, seed_off=5)
+    by_ws = ops.attention_bwd(q, k, v, o, do, lse, B, T, nh, small, drop_p=0.1, seed=11, seed_off=5)
+    lib().set_debug_flags(0x01000000)
+    try:
+        by_flag = ops.attention_bwd(q, k, v, o, do, lse, B, T, nh, big, drop_p=0.1, seed=11, seed_off=5)
+    finally:
+        lib().set_debug_flags(0)
+    for a, b2, c in zip(hand, by_ws, by_flag):
+        scale = c.abs().max().item()
+        assert (a - c).abs().max().item() < 2e-5 * scale      # same mask, same math, other summation order
+        assert (b2 - c).abs().max().item() < 2e-5 * scale
+        assert torch.isfinite(a).all()
+
+
 @pytest.mark.parametrize("hd,T", [(16, 962), (128, 77)])
 def test_attention_fused_qkv_layout(dev, hd, T):
     """q/k/v and dq/dk/dv as column blocks of one [M, 3C] matrix (the fused key|query|value projection of the model)

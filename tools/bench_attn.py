@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 ws = ops.Workspace(dev, 1 << 30)
 from deepsense6g_tii_amd._lib import lib
 lib().set_compute_mode(int(os.environ.get('BF16', '0')))
-lib().set_debug_flags(int(os.environ.get('DBG', '0')))
+lib().set_debug_flags(int(os.environ.get('DBG', '0'), 0))
 B, T, nh = int(os.environ.get("B", "12")), 962, 4
 reps = int(os.environ.get("REPS", "10"))
 

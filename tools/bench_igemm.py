@@ -24,7 +24,7 @@ reps = int(os.environ.get("REPS", "5"))
 only = os.environ.get("ONLY")
 if os.environ.get("ZERO"):  # all-zero operands: same instruction stream, minimal data toggling (power experiment)
     torch.randn = lambda *a, **k: torch.zeros(*a, **{kk: vv for kk, vv in k.items() if kk != "generator"})
-lib().set_debug_flags(int(os.environ.get("DBG", "0")))
+lib().set_debug_flags(int(os.environ.get("DBG", "0"), 0))
 lib().set_compute_mode(int(os.environ.get("BF16", "0")))
 
 def timeit(fn):
