@@ -16,8 +16,11 @@ ap.add_argument("--lr", type=float, default=1e-4)
 ap.add_argument("--pool", type=int, default=16, help="distinct training batches (seeds)")
 ap.add_argument("--eval-batches", type=int, default=8)
 ap.add_argument("--ema", type=int, default=0)
+ap.add_argument("--dtype", default="f32", help="matrix-core mode (ops.set_compute_mode)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
+from deepsense6g_tii_amd import ops
+ops.set_compute_mode(args.dtype)
 torch.manual_seed(100)
 cfg = GlobalConfig()
 model = TransFuser(cfg, dev)
