@@ -35,7 +35,8 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2* out) {
     }
 }
 
-template <int PLANES>
+// ABL (timing ablations, results wrong): 1 no global loads / staging, 2 no MFMAs, 3 no fragment reads
+template <int PLANES, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                             float* __restrict__ C, int M, int N, int K) {
     // plane image: [row 128][32 bf16] = 64 B per row, 16-B chunk index XOR-swizzled by (row >> 1) & 3
@@ -83,21 +84,27 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restr
     const int nk = K / BK;
     gload(0);
     for (int kt = 0; kt < nk; ++kt) {
-        stage();
+        if (ABL != 1) stage();
         __syncthreads();
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+        if (ABL != 1 && kt + 1 < nk) gload((kt + 1) * BK);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             bf16x8 a[2][PLANES], b[2][PLANES];
+            if (ABL == 3) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int p = 0; p < PLANES; ++p) { a[i][p] = __builtin_bit_cast(bf16x8, ra[i]); b[i][p] = __builtin_bit_cast(bf16x8, rb[i]); }
+            }
+#pragma unroll
+            for (int i = 0; i < 2 && ABL != 3; ++i) {
                 const int row = wm * 64 + i * 32 + l31;
                 const int off = row * 64 + (((2 * q + khalf) ^ ((row >> 1) & 3)) << 4);
 #pragma unroll
                 for (int p = 0; p < PLANES; ++p) a[i][p] = *reinterpret_cast<const bf16x8*>(&As[p][off]);
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < 2 && ABL != 3; ++j) {
                 const int row = wn * 64 + j * 32 + l31;
                 const int off = row * 64 + (((2 * q + khalf) ^ ((row >> 1) & 3)) << 4);
 #pragma unroll
@@ -114,7 +121,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restr
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
+                            if (ABL != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
+                            else acc[i][j][0] += (float)a[i][pa][0] * (float)b[j][pb][0];
                 }
             }
         }
@@ -132,9 +140,109 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restr
             }
 }
 
+// Second form: two LDS buffers, ONE barrier per k-tile; the split + LDS writes of tile t+1 sit in the same basic block
+// as the MFMA chain of tile t, so the scheduler can issue the VALU work in the shadow of the matrix pipe.
+template <int PLANES>
+__global__ __launch_bounds__(256, PLANES == 3 ? 1 : 2) void gemm_split_db_kernel(const float* __restrict__ A,
+                                                                                 const float* __restrict__ B,
+                                                                                 float* __restrict__ C, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][PLANES][BM * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][PLANES][BN * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, khalf = lane >> 5;
+    const int tiles_n = N / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * 256, row = c >> 3, kc = c & 7;
+            ra[i] = *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + row) * K + k0 + kc * 4);
+            rb[i] = *reinterpret_cast<const f32x4*>(B + (size_t)(n0 + row) * K + k0 + kc * 4);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * 256, row = c >> 3, kc = c & 7;
+            const int off = row * 64 + ((((kc >> 1) ^ ((row >> 1) & 3)) << 4) | ((kc & 1) << 3));
+            u32x2 pa[PLANES], pb[PLANES];
+            split4<PLANES>(ra[i], pa);
+            split4<PLANES>(rb[i], pb);
+#pragma unroll
+            for (int p = 0; p < PLANES; ++p) {
+                *reinterpret_cast<u32x2*>(&As[buf][p][off]) = pa[p];
+                *reinterpret_cast<u32x2*>(&Bs[buf][p][off]) = pb[p];
+            }
+        }
+    };
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            bf16x8 a[2][PLANES], b[2][PLANES];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32 + l31;
+                const int off = row * 64 + (((2 * q + khalf) ^ ((row >> 1) & 3)) << 4);
+#pragma unroll
+                for (int p = 0; p < PLANES; ++p) a[i][p] = *reinterpret_cast<const bf16x8*>(&As[buf][p][off]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn * 64 + j * 32 + l31;
+                const int off = row * 64 + (((2 * q + khalf) ^ ((row >> 1) & 3)) << 4);
+#pragma unroll
+                for (int p = 0; p < PLANES; ++p) b[j][p] = *reinterpret_cast<const bf16x8*>(&Bs[buf][p][off]);
+            }
+#pragma unroll
+            for (int s = (PLANES == 3 ? 2 : PLANES - 1); s >= 0; --s) {
+#pragma unroll
+                for (int pa = 0; pa < PLANES; ++pa) {
+                    const int pb = s - pa;
+                    if (pb < 0 || pb >= PLANES) continue;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+    const int nk = K / BK;
+    gload(0);
+    stage(0);
+    if (nk > 1) gload(BK);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(buf ^ 1);          // regs hold tile kt+1 (loaded during the previous iteration)
+        if (kt + 2 < nk) gload((kt + 2) * BK);    // lands during this and the next compute phase
+        compute(buf);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const int col = n0 + wn * 64 + j * 32 + l31;
+                C[(size_t)row * N + col] = acc[i][j][r];
+            }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-template <int PLANES>
+template <int PLANES, int ABL = 0>
 void run(int M, int N, int K, bool check) {
     std::vector<float> ha((size_t)M * K), hb((size_t)N * K);
     unsigned s = 12345u;
@@ -146,7 +254,8 @@ void run(int M, int N, int K, bool check) {
     CK(hipMemcpy(dA, ha.data(), ha.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dB, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
     dim3 grid((M / BM) * (N / BN)), block(256);
-    hipLaunchKernelGGL((gemm_split_kernel<PLANES>), grid, block, 0, 0, dA, dB, dC, M, N, K);
+    if (ABL == 9) hipLaunchKernelGGL((gemm_split_db_kernel<PLANES>), grid, block, 0, 0, dA, dB, dC, M, N, K);
+    else hipLaunchKernelGGL((gemm_split_kernel<PLANES, ABL == 9 ? 0 : ABL>), grid, block, 0, 0, dA, dB, dC, M, N, K);
     CK(hipDeviceSynchronize());
     if (check) {
         std::vector<float> hc((size_t)M * N);
@@ -165,13 +274,16 @@ void run(int M, int N, int K, bool check) {
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         const int reps = 20;
         CK(hipEventRecord(e0));
-        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((gemm_split_kernel<PLANES>), grid, block, 0, 0, dA, dB, dC, M, N, K);
+        for (int r = 0; r < reps; ++r) {
+            if (ABL == 9) hipLaunchKernelGGL((gemm_split_db_kernel<PLANES>), grid, block, 0, 0, dA, dB, dC, M, N, K);
+            else hipLaunchKernelGGL((gemm_split_kernel<PLANES, ABL == 9 ? 0 : ABL>), grid, block, 0, 0, dA, dB, dC, M, N, K);
+        }
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / reps;
-        printf("planes %d  M %5d N %4d K %4d  %8.1f us  %6.1f TFLOP/s (algorithmic)\n", PLANES, M, N, K, us,
+        printf("planes %d abl %d  M %5d N %4d K %4d  %8.1f us  %6.1f TFLOP/s (algorithmic)\n", PLANES, ABL, M, N, K, us,
                2.0 * M * N * K / us / 1e6);
     }
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
@@ -181,11 +293,21 @@ int main() {
     run<3>(256, 256, 128, true);
     run<2>(256, 256, 128, true);
     run<3>(384, 128, 2048, true);
+    run<3, 9>(384, 128, 2048, true);
+    run<2, 9>(256, 256, 128, true);
     const int shapes[][3] = {{11520, 2048, 512}, {11520, 512, 2048}, {11520, 1536, 512}, {11520, 512, 512}, {12288, 4096, 4096}};
     for (auto& sh : shapes) {
         run<3>(sh[0], sh[1], sh[2], false);
         run<2>(sh[0], sh[1], sh[2], false);
         run<1>(sh[0], sh[1], sh[2], false);
+        run<3, 9>(sh[0], sh[1], sh[2], false);
+        run<2, 9>(sh[0], sh[1], sh[2], false);
+        run<1, 9>(sh[0], sh[1], sh[2], false);
+    }
+    if (getenv("ABLATE")) {
+        run<3, 1>(12288, 4096, 4096, false); run<3, 2>(12288, 4096, 4096, false); run<3, 3>(12288, 4096, 4096, false);
+        run<2, 1>(12288, 4096, 4096, false); run<2, 2>(12288, 4096, 4096, false); run<2, 3>(12288, 4096, 4096, false);
+        run<1, 1>(12288, 4096, 4096, false); run<1, 2>(12288, 4096, 4096, false); run<1, 3>(12288, 4096, 4096, false);
     }
     return 0;
 }
