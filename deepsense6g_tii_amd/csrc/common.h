@@ -43,6 +43,41 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 extern int g_ds6g_bf16;
 
 #ifdef __HIPCC__
+// BN output before the activation, ONE spelling shared by the forward kernels (bn_apply, the fused BN + ReLU + max-pool of
+// the stem) and by the backward kernels that re-derive the ReLU mask from it instead of reading the activation tensor
+// (identical rounding -> identical mask)
+__device__ __forceinline__ f32x4 bn_affine(const f32x4 x, const f32x4 mu, const f32x4 is, const f32x4 g, const f32x4 b) {
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = fmaf((x[j] - mu[j]) * is[j], g[j], b[j]);
+    return r;
+}
+// gradient of a 3x3 / stride 2 / pad 1 max-pool gathered on the fly: row = (n*H + h)*W + w of the pool INPUT; the up to
+// four windows covering that pixel contribute where their stored argmax (r*3 + s, one byte per channel) points at it
+struct PoolGrad { const float* dp; const uint8_t* idx; int H, W, Ho, Wo; };
+__device__ __forceinline__ f32x4 pooled_grad(const PoolGrad& pg, long row, int c4, int C) {
+    const int w = (int)(row % pg.W);
+    const long t = row / pg.W;
+    const int h = (int)(t % pg.H);
+    const long n = t / pg.H;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int oh = h >> 1; oh <= (h + 1) >> 1; ++oh) {
+        if (oh >= pg.Ho) continue;
+        const int r = h - (oh * 2 - 1);
+        for (int ow = w >> 1; ow <= (w + 1) >> 1; ++ow) {
+            if (ow >= pg.Wo) continue;
+            const int s = w - (ow * 2 - 1);
+            const long o = ((n * pg.Ho + oh) * pg.Wo + ow) * C + c4;
+            const uint32_t pk = *reinterpret_cast<const uint32_t*>(pg.idx + o);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(pg.dp + o);
+            const uint32_t me = (uint32_t)(r * 3 + s);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (((pk >> (8 * j)) & 0xff) == me) acc[j] += g[j];
+        }
+    }
+    return acc;
+}
 // a ~= hi + lo with hi = bf16(a) (RNE), lo = bf16(a - hi): |a - hi - lo| <= 2^-16 |a|
 __device__ __forceinline__ void split_bf16x8(const float* f, bf16x8& hi, bf16x8& lo) {
 #pragma unroll

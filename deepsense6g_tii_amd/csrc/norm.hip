@@ -14,15 +14,6 @@ constexpr int BN_ROWS_PER_THREAD = 16;
 constexpr int FIN_COLS = 8;
 constexpr int FIN_GROUPS = 32;
 
-// BN output before the activation, ONE spelling shared by the forward (bn_apply) and by the backward kernels that
-// re-derive the ReLU mask from it instead of reading the activation tensor (identical rounding -> identical mask)
-__device__ __forceinline__ f32x4 bn_affine(const f32x4 x, const f32x4 mu, const f32x4 is, const f32x4 g, const f32x4 b) {
-    f32x4 r;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = fmaf((x[j] - mu[j]) * is[j], g[j], b[j]);
-    return r;
-}
-
 // partial[blk][0][c] = sum_rows a(r,c), partial[blk][1][c] = sum_rows b(r,c) in fp64.
 // MODE 0: a = x, b = x*x.   MODE 1: a = dyeff, b = dyeff * xhat  (BN backward)
 template <int MODE>
@@ -31,7 +22,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, long M, int C,
                                                         int rows_per_block, double* __restrict__ partial,
-                                                        const float* __restrict__ mg, const float* __restrict__ mb) {
+                                                        const float* __restrict__ mg, const float* __restrict__ mb,
+                                                        const PoolGrad pg) {
     extern __shared__ __attribute__((aligned(16))) double red[];  // [rowlanes][2][C]
     const int cg = C >> 2;
     const int colg = threadIdx.x % cg;
@@ -57,7 +49,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
             s1 += xv;
             s2 += xv * xv;
         } else {
-            f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+            f32x4 g = pg.dp ? pooled_grad(pg, r, colg * 4, C) : *reinterpret_cast<const f32x4*>(dy + o);
             if (y_mask || mg) {
                 const f32x4 yv = mg ? bn_affine(xv, mu, is, gam, bet) : *reinterpret_cast<const f32x4*>(y_mask + o);
 #pragma unroll
@@ -191,7 +183,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, float* __restrict__ dx,
                                                            float* __restrict__ dres, long total4, int C,
-                                                           const float* __restrict__ mg, const float* __restrict__ mb) {
+                                                           const float* __restrict__ mg, const float* __restrict__ mb,
+                                                           const PoolGrad pg) {
     const int cg = C >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % cg) * 4;
@@ -200,7 +193,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const f32x4 a = *reinterpret_cast<const f32x4*>(coef + c4);
         const f32x4 b = *reinterpret_cast<const f32x4*>(coef + C + c4);
         const f32x4 cc = *reinterpret_cast<const f32x4*>(coef + 2 * C + c4);
-        f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
+        f32x4 g = pg.dp ? pooled_grad(pg, i / cg, c4, C) : *reinterpret_cast<const f32x4*>(dy + i * 4);
         const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
         if (y_mask || mg) {
             const f32x4 yv = mg ? bn_affine(xv, mu, is, *reinterpret_cast<const f32x4*>(mg + c4),
@@ -437,7 +430,7 @@ int ds6g_bn_stats(const float* x, long M, int C, float eps, float momentum, floa
     double* partial = (double*)ws;
     const size_t lds = (size_t)(256 / (C / 4)) * 2 * C * sizeof(double);
     hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, x, nullptr, nullptr,
-                       nullptr, nullptr, M, C, rpb, partial, nullptr, nullptr);
+                       nullptr, nullptr, M, C, rpb, partial, nullptr, nullptr, PoolGrad{});
     DS6G_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk,
                        M, C, eps, momentum, mean, invstd, running_mean, running_var);
@@ -471,21 +464,19 @@ int ds6g_bn_apply(const float* x, const float* mean, const float* invstd, const 
 // dgamma/dbeta (+)=; dres (nullable) receives dyeff (gradient of the residual branch).
 // relu_beta (nullable, with y_mask NULL): the BN was followed by ReLU with NO residual added in between - the mask is
 // re-derived as (gamma * xhat + relu_beta > 0) from x, which the kernels read anyway, instead of reading the activation
-int ds6g_bn_bwd(const float* dy, const float* y_mask, const float* x, const float* mean, const float* invstd,
-                const float* gamma, const float* relu_beta, float* dx, float* dgamma, float* dbeta, float* dres, long M,
-                int C, int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream) {
-    DS6G_ENTER();
-    DS6G_CHECK_ARG(!(y_mask && relu_beta));
+static int bn_bwd_run(const float* dy, const PoolGrad pg, const float* y_mask, const float* x, const float* mean,
+                      const float* invstd, const float* gamma, const float* relu_beta, float* dx, float* dgamma,
+                      float* dbeta, float* dres, long M, int C, int accumulate_param_grads, void* ws, size_t ws_bytes,
+                      void* stream) {
     const float* mg = relu_beta ? gamma : nullptr;
     int rpb, nblk;
-    DS6G_CHECK_ARG(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && ws);
     DS6G_CHECK_ARG(bn_geometry(M, C, &rpb, &nblk) == DS6G_OK);
     DS6G_CHECK_ARG(ws_bytes >= ds6g_bn_workspace_bytes(M, C));
     double* partial = (double*)ws;
     float* coef = (float*)((char*)ws + (size_t)nblk * 2 * C * sizeof(double));
     const size_t lds = (size_t)(256 / (C / 4)) * 2 * C * sizeof(double);
     hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, x, dy, y_mask, mean,
-                       invstd, M, C, rpb, partial, mg, relu_beta);
+                       invstd, M, C, rpb, partial, mg, relu_beta, pg);
     DS6G_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk, M,
                        C, gamma, invstd, dgamma, dbeta, coef, accumulate_param_grads);
@@ -493,9 +484,33 @@ int ds6g_bn_bwd(const float* dy, const float* y_mask, const float* x, const floa
     const long total4 = M * C / 4;
     const int grid = (int)min((long)8192, (total4 + 255) / 256);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, y_mask, x, mean,
-                       invstd, coef, dx, dres, total4, C, mg, relu_beta);
+                       invstd, coef, dx, dres, total4, C, mg, relu_beta, pg);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
+}
+
+int ds6g_bn_bwd(const float* dy, const float* y_mask, const float* x, const float* mean, const float* invstd,
+                const float* gamma, const float* relu_beta, float* dx, float* dgamma, float* dbeta, float* dres, long M,
+                int C, int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(!(y_mask && relu_beta));
+    DS6G_CHECK_ARG(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && ws);
+    return bn_bwd_run(dy, PoolGrad{}, y_mask, x, mean, invstd, gamma, relu_beta, dx, dgamma, dbeta, dres, M, C,
+                      accumulate_param_grads, ws, ws_bytes, stream);
+}
+
+// BN -> ReLU -> 3x3/2 max-pool (the ResNet stem, model2_seq.py:495-500 via torchvision) backward in one pass over x: the
+// pool gradient is gathered from (dpool, idx) where the BN kernels would read dy, so the dense [N][H][W][C] gradient of
+// the pool input is never written or read
+int ds6g_bn_bwd_maxpool(const float* dpool, const uint8_t* idx, const float* x, const float* mean, const float* invstd,
+                        const float* gamma, const float* relu_beta, float* dx, float* dgamma, float* dbeta, int N, int H,
+                        int W, int C, int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(dpool && idx && x && mean && invstd && gamma && relu_beta && dx && dgamma && dbeta && ws);
+    DS6G_CHECK_ARG(N > 0 && H > 0 && W > 0 && C % 4 == 0);
+    const PoolGrad pg{dpool, idx, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1};
+    return bn_bwd_run(nullptr, pg, nullptr, x, mean, invstd, gamma, relu_beta, dx, dgamma, dbeta, nullptr,
+                      (long)N * H * W, C, accumulate_param_grads, ws, ws_bytes, stream);
 }
 
 int ds6g_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

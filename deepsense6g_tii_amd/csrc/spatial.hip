@@ -60,9 +60,13 @@ __global__ void pad_channels_kernel(const float* __restrict__ src, float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// bn_mean != NULL: the pooled tensor is relu(BN(x)), evaluated on the fly (the activation is never materialised)
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           uint8_t* __restrict__ idx, int N, int H, int W, int C,
-                                                          int Ho, int Wo) {
+                                                          int Ho, int Wo, const float* __restrict__ bn_mean,
+                                                          const float* __restrict__ bn_invstd,
+                                                          const float* __restrict__ bn_gamma,
+                                                          const float* __restrict__ bn_beta) {
     const int cg = C >> 2;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)N * Ho * Wo * cg) return;
@@ -73,13 +77,25 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     const int n = (int)(t / Ho);
     f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int bi[4] = {0, 0, 0, 0};
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = mu, gam = mu, bet = mu;
+    if (bn_mean) {
+        mu = *reinterpret_cast<const f32x4*>(bn_mean + c4);
+        is = *reinterpret_cast<const f32x4*>(bn_invstd + c4);
+        gam = *reinterpret_cast<const f32x4*>(bn_gamma + c4);
+        bet = *reinterpret_cast<const f32x4*>(bn_beta + c4);
+    }
     for (int r = 0; r < 3; ++r) {
         const int ih = oh * 2 - 1 + r;
         if (ih < 0 || ih >= H) continue;
         for (int s = 0; s < 3; ++s) {
             const int iw = ow * 2 - 1 + s;
             if (iw < 0 || iw >= W) continue;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long)n * H + ih) * W + iw) * C + c4);
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long)n * H + ih) * W + iw) * C + c4);
+            if (bn_mean) {
+                v = bn_affine(v, mu, is, gam, bet);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (v[j] > best[j] || v[j] != v[j]) { best[j] = v[j]; bi[j] = r * 3 + s; }
@@ -424,7 +440,21 @@ int ds6g_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, 
     DS6G_CHECK_ARG(x && y && idx && C % 4 == 0);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid1((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
-                       (hipStream_t)stream, x, y, idx, N, H, W, C, Ho, Wo);
+                       (hipStream_t)stream, x, y, idx, N, H, W, C, Ho, Wo, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+// y = maxpool3x3/2(relu(BN(x))) with the per-channel (mean, invstd) of ds6g_bn_stats / ds6g_bn_eval_prepare: the stem's
+// BN -> ReLU -> MaxPool in one pass, bit-identical to ds6g_bn_apply(relu) followed by ds6g_maxpool3x3s2_fwd
+int ds6g_bn_relu_maxpool3x3s2_fwd(const float* x, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && mean && invstd && gamma && beta && y && idx && C % 4 == 0 && N > 0 && H > 0 && W > 0);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid1((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, x, y, idx, N, H, W, C, Ho, Wo, mean, invstd, gamma, beta);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }

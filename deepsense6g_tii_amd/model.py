@@ -544,7 +544,17 @@ class TransFuser(nn.Module):
             wpad = torch.empty((64, 7, 7, 4), dtype=F32, device=self.device)
             L.pad_channels(self._w(trunk.conv1.weight), wpad.data_ptr(), 64 * 49, cin, 4, 0, 0, st)
             c1 = ops.conv2d_fwd(x, wpad.data_ptr(), 64, 7, 7, 2, 3)
-            a1, st1 = self._bn_fwd(trunk.bn1, c1, True, None, train)
+            # BN -> ReLU -> max-pool in one pass: the [N, 128, 128, 64] activation is never materialised
+            bn = trunk.bn1
+            stats = torch.empty(2, 64, dtype=F32, device=self.device)
+            if train:
+                ops.bn_stats(c1.numel() // 64, 64, c1, stats[0], stats[1], bn.running_mean.data_ptr(),
+                             bn.running_var.data_ptr(), self._ws, bn.eps, bn.momentum)
+            else:
+                ops.bn_eval_prepare(bn.running_mean.data_ptr(), bn.running_var.data_ptr(), 64, stats[0], stats[1], bn.eps)
+            st1 = (stats[0], stats[1])
+            p1, idx = ops.bn_relu_maxpool(c1, st1[0], st1[1], self._w(bn.weight), self._w(bn.bias))
+            return p1, (x, c1, None, st1, idx, cin)
         N, H1, W1, _ = a1.shape
         Ho, Wo = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
         p1 = torch.empty((N, Ho, Wo, 64), dtype=F32, device=self.device)
@@ -964,11 +974,12 @@ class TransFuser(nn.Module):
     def _stem_bwd(self, trunk, ctx, dpool, cin):
         L = lib()
         st = ops._stream()
-        x, c1, a1, st1, idx, _ = ctx
-        N, H1, W1, _ = a1.shape
-        da1 = torch.empty_like(a1)
-        L.maxpool3x3s2_bwd(dpool.data_ptr(), idx.data_ptr(), da1.data_ptr(), N, H1, W1, 64, st)
-        dc1, _ = self._bn_bwd(trunk.bn1, da1, a1, c1, st1, relu_no_residual=True)
+        x, c1, _, st1, idx, _ = ctx
+        bn = trunk.bn1
+        gw_bn, a_bn = self._g(bn.weight)
+        gb_bn, _ = self._g(bn.bias)
+        dc1 = ops.bn_bwd_maxpool(dpool, idx, c1, st1[0], st1[1], self._w(bn.weight), self._w(bn.bias), gw_bn, gb_bn,
+                                 self._ws, accumulate=bool(a_bn))
         dwpad = torch.empty((64, 7, 7, 4), dtype=F32, device=self.device)
         gw, aw = self._g(trunk.conv1.weight)
 

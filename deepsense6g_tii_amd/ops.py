@@ -225,6 +225,29 @@ def bn_bwd(dy, y_mask, x, mean, invstd, gamma_ptr, dgamma_ptr, dbeta_ptr, ws: Wo
     return dx, dres
 
 
+def bn_relu_maxpool(x, mean, invstd, gamma_ptr, beta_ptr):
+    """maxpool3x3/2(relu(BN(x))) in one pass (the stem) -> (pooled [N, Ho, Wo, C], argmax index uint8)"""
+    N, H, W, C = x.shape
+    _chk(x)
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((N, Ho, Wo, C), dtype=F32, device=x.device)
+    idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+    lib().bn_relu_maxpool3x3s2_fwd(_p(x), _p(mean), _p(invstd), gamma_ptr, beta_ptr, _p(y), _p(idx), N, H, W, C, _stream())
+    return y, idx
+
+
+def bn_bwd_maxpool(dpool, idx, x, mean, invstd, gamma_ptr, beta_ptr, dgamma_ptr, dbeta_ptr, ws: Workspace, accumulate=False):
+    """backward of bn_relu_maxpool: dx of the BN input from the gradient of the pooled tensor (ReLU mask recomputed from
+    x, pool gradient gathered from (dpool, idx) inside the BN kernels)"""
+    N, H, W, C = x.shape
+    _chk(x)
+    _chk(dpool, N, (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1, C)
+    dx = torch.empty_like(x)
+    lib().bn_bwd_maxpool(_p(dpool), _p(idx), _p(x), _p(mean), _p(invstd), gamma_ptr, beta_ptr, _p(dx), dgamma_ptr, dbeta_ptr,
+                         N, H, W, C, int(accumulate), ws.ptr, ws.nbytes, _stream())
+    return dx
+
+
 def layernorm_fwd(x, gamma_ptr, beta_ptr, eps=1e-5):
     M, C = x.shape
     _chk(x)

@@ -190,6 +190,15 @@ int ds6g_pad_channels(const float* src, float* dst, long rows, int cin, int cout
 /* MaxPool2d(3,2,1) of the stems: model2_seq.py:498,503,508 */
 int ds6g_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream);
 int ds6g_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, void* stream);
+/* the ResNet stem's BN -> ReLU -> MaxPool(3, 2, 1) (torchvision resnet.py forward, used at model2_seq.py:495-500) without
+ * materialising the activation: forward = ds6g_bn_apply(relu) + ds6g_maxpool3x3s2_fwd in one pass (bit-identical);
+ * backward = ds6g_maxpool3x3s2_bwd + ds6g_bn_bwd(relu_beta) with the pool gradient gathered from (dpool, idx) inside the
+ * BN kernels.  x: the conv output [N][H][W][C]; mean / invstd from ds6g_bn_stats or ds6g_bn_eval_prepare. */
+int ds6g_bn_relu_maxpool3x3s2_fwd(const float* x, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream);
+int ds6g_bn_bwd_maxpool(const float* dpool, const uint8_t* idx, const float* x, const float* mean, const float* invstd,
+                        const float* gamma, const float* relu_beta, float* dx, float* dgamma, float* dbeta, int N, int H,
+                        int W, int C, int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream);
 /* AdaptiveAvgPool2d((8,8)) + token pack + pos_emb + embd dropout: model2_seq.py:414,515-517,261-272 */
 int ds6g_avgpool_tokens_fwd(const float* feat, const float* pos_emb, float* tokens, int N, int H, int C,
                             int frames_per_sample, int mod_off, int T, float drop_p, uint64_t seed,

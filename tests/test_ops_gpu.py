@@ -643,3 +643,51 @@ def test_winograd_wgrad3x3(dev, N, H, W, C, K):
     acc = base.clone()
     ops.conv3x3_winograd_wgrad(xg, dyg, acc.data_ptr(), ws, accumulate=True)
     close((acc - base).cpu().permute(0, 3, 1, 2), w.grad, 2e-5, 2e-5)
+
+
+def test_stem_bn_relu_maxpool_fused(dev):
+    """The stem's BN -> ReLU -> MaxPool(3, 2, 1) in one pass: forward bit-identical to bn_apply(relu) + maxpool, backward
+    (pool gradient gathered inside the BN kernels) equal to maxpool_bwd + bn_bwd and to torch autograd."""
+    from deepsense6g_tii_amd._lib import lib
+    ops = _ops()
+    L = lib()
+    N, H, W, C = 3, 18, 22, 64
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(N, C, H, W, generator=g)
+    x[:, :8] = x[:, :8].round()   # exact ties inside pooling windows
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.3
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = F.max_pool2d(F.relu(F.batch_norm(xr, None, None, gr, br, training=True, eps=1e-5)), 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xg = nhwc(x)
+    gg, bg = gamma.cuda(), beta.cuda()
+    ws = ops.Workspace(dev, 64 << 20)
+    stats = torch.empty(2, C, device=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    ops.bn_stats(N * H * W, C, xg, stats[0], stats[1], rm.data_ptr(), rv.data_ptr(), ws, 1e-5, 0.1)
+    # unfused pair
+    a = ops.bn_apply(xg, stats[0], stats[1], gg.data_ptr(), bg.data_ptr(), True, None)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    p_ref = torch.empty(N, Ho, Wo, C, device=dev)
+    i_ref = torch.empty(N, Ho, Wo, C, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    L.maxpool3x3s2_fwd(a.data_ptr(), p_ref.data_ptr(), i_ref.data_ptr(), N, H, W, C, st)
+    # fused
+    p, idx = ops.bn_relu_maxpool(xg, stats[0], stats[1], gg.data_ptr(), bg.data_ptr())
+    assert torch.equal(p, p_ref) and torch.equal(idx, i_ref)
+    close(p.cpu().permute(0, 3, 1, 2), y.detach(), 1e-4, 1e-5)
+    dyg = nhwc(dy)
+    da = torch.empty_like(a)
+    L.maxpool3x3s2_bwd(dyg.data_ptr(), i_ref.data_ptr(), da.data_ptr(), N, H, W, C, st)
+    dgam_ref, dbet_ref = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dx_ref, _ = ops.bn_bwd(da, None, xg, stats[0], stats[1], gg.data_ptr(), dgam_ref.data_ptr(), dbet_ref.data_ptr(), ws,
+                           relu_beta_ptr=bg.data_ptr())
+    dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dx = ops.bn_bwd_maxpool(dyg, idx, xg, stats[0], stats[1], gg.data_ptr(), bg.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), ws)
+    assert torch.equal(dx, dx_ref) and torch.equal(dgam, dgam_ref) and torch.equal(dbet, dbet_ref)
+    close(dx.cpu().permute(0, 3, 1, 2), xr.grad, 1e-4, 2e-5)
+    close(dgam.cpu(), gr.grad, 1e-4, 1e-5)
+    close(dbet.cpu(), br.grad, 1e-4, 1e-5)
