@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (sequences)")
     ap.add_argument("--ema", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt-modes", action="store_true", help="skip the extra f32x3 timing beside the exact-fp32 value")
+    ap.add_argument("--no-alt-modes", action="store_true", help="skip the extra f32x3 / f32x6 timings beside the exact-fp32 value")
     ap.add_argument("--dtype", choices=("f32", "bf16", "f32x3", "f32x6"), default="f32",
                     help="matrix-core mode: f32 = exact fp32 MFMA (parity path, default); bf16 = operands rounded to bf16, "
                          "fp32 accumulate/storage (BASELINE configs[1]-style throughput configuration); f32x3 = split bf16 "
@@ -253,41 +253,45 @@ def main():
                                                                            tflops=round(a[1] / (a[2] * 1e-3) / 1e12, 2))
                                                 for v, a in sorted(agg.items())})
 
-    # ---- the split-bf16 matrix-core mode next to the exact one (same model / batch / timing protocol; reported beside
-    # `value`, never as it): a*b = hi*hi + hi*lo + lo*hi on the bf16 matrix cores, ~2^-16 relative product error ----
+    # ---- the split-bf16 matrix-core modes next to the exact one (same model / batch / timing protocol; reported beside
+    # `value`, never as it) ----
     alt = None
     if args.dtype == "f32" and not args.no_alt_modes:
-        try:
-            with torch.no_grad():
-                model.eval()
-                ref_logits = model(fronts, lidars, radars, gps).float().clone()
-                ops.set_compute_mode("f32x3")
-                x3_logits = model(fronts, lidars, radars, gps).float()
-                dev_rel = float((x3_logits - ref_logits).abs().max() / ref_logits.abs().max())
+        what = {"f32x3": "split-bf16 products (hi*hi + hi*lo + lo*hi, ~2^-16), fp32 accumulate and storage; "
+                         "ds6g_set_compute_mode(2); Winograd off (direct implicit GEMM); tests/test_bf16_gpu.py",
+                "f32x6": "three-way bf16 split, six products (fp32-grade, ~2^-23) in the direct kernels and attention, fp32 "
+                         "Winograd kept for the 3x3/1 convs; ds6g_set_compute_mode(3); tests/test_bf16_gpu.py"}
+        alt = {}
+        for mode in ("f32x3", "f32x6"):
+            try:
+                with torch.no_grad():
+                    model.eval()
+                    ops.set_compute_mode("f32")
+                    ref_logits = model(fronts, lidars, radars, gps).float().clone()
+                    ops.set_compute_mode(mode)
+                    m_logits = model(fronts, lidars, radars, gps).float()
+                    dev_rel = float((m_logits - ref_logits).abs().max() / ref_logits.abs().max())
+                    model.train()
+                for _ in range(2):
+                    train_iteration(model, opt, batch, ema, reducer)
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    train_iteration(model, opt, batch, ema, reducer)
+                sync()
+                el = time.perf_counter() - t0
+                if world > 1:
+                    t = torch.tensor([el], device=dev, dtype=torch.float64)
+                    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                    el = float(t.item())
+                alt[mode] = {"value": args.batch * world * args.steps / el, "unit": "samples/s",
+                             "ms_per_step": el / args.steps * 1e3, "eval_logits_max_dev_vs_f32_rel": dev_rel,
+                             "what": what[mode]}
+            except Exception as e:  # an extra mode never takes the headline line down with it
+                alt[mode] = {"error": repr(e)}
+            finally:
+                ops.set_compute_mode("f32")
                 model.train()
-            for _ in range(2):
-                train_iteration(model, opt, batch, ema, reducer)
-            sync()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                train_iteration(model, opt, batch, ema, reducer)
-            sync()
-            el3 = time.perf_counter() - t0
-            if world > 1:
-                t = torch.tensor([el3], device=dev, dtype=torch.float64)
-                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-                el3 = float(t.item())
-            alt = {"f32x3": {"value": args.batch * world * args.steps / el3, "unit": "samples/s",
-                             "ms_per_step": el3 / args.steps * 1e3,
-                             "eval_logits_max_dev_vs_f32_rel": dev_rel,
-                             "what": "split-bf16 products (hi*hi + hi*lo + lo*hi), fp32 accumulate and storage; "
-                                     "ds6g_set_compute_mode(2); Winograd off (direct implicit GEMM); "
-                                     "tests/test_bf16_gpu.py"}}
-        except Exception as e:  # the extra mode never takes the headline line down with it
-            alt = {"f32x3": {"error": repr(e)}}
-        finally:
-            ops.set_compute_mode("f32")
-            model.train()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

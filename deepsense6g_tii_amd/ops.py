@@ -82,7 +82,9 @@ def bn_fold(w_ohwi_ptr, bn, K, taps, cin, cpad=None):
 def winograd_ok(x_shape, K):
     """3x3 / stride 1 / pad 1 conv of an NHWC tensor of this shape to K channels can run as Winograd F(2x2, 3x3)"""
     N, H, W, C = x_shape
-    return bool(lib().winograd_supported(N, H, W, C, K)) and lib().get_compute_mode() == 0
+    # exact-fp32 products only: the default mode, and f32x6 (fp32-grade: its direct kernels use the six-product split, its
+    # 3x3 / stride-1 convs stay on the fp32 Winograd kernel, which is faster than the split direct form)
+    return bool(lib().winograd_supported(N, H, W, C, K)) and lib().get_compute_mode() in (0, 3)
 
 
 def winograd_weights(w_ohwi_ptr, K, C, device, dgrad=False, both=False):
@@ -117,7 +119,7 @@ def conv3x3_winograd_bias_act(x, u, bias_ptr, K, relu=0, residual=None):
 
 def winograd_wgrad_ok(x_shape, K):
     N, H, W, C = x_shape
-    return bool(lib().winograd_wgrad_supported(N, H, W, C, K)) and lib().get_compute_mode() == 0
+    return bool(lib().winograd_wgrad_supported(N, H, W, C, K)) and lib().get_compute_mode() in (0, 3)
 
 
 def conv3x3_winograd_wgrad(x, dy, dw_ohwi_ptr, ws: Workspace, accumulate=False):
