@@ -240,6 +240,109 @@ __global__ __launch_bounds__(256, PLANES == 3 ? 1 : 2) void gemm_split_db_kernel
             }
 }
 
+// Third form: 256 x 128 tile, 8 waves (4 x 2, 64 x 64 each): 42.7 flop per L2 byte instead of 32, and the staging work
+// (split + LDS writes) per MFMA is 3/4 of the 128 x 128 form.  Single LDS buffer, two barriers per k-tile.
+template <int PLANES>
+__global__ __launch_bounds__(512, 1) void gemm_split_256_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                                float* __restrict__ C, int M, int N, int K) {
+    constexpr int TM_ = 256, TN_ = 128;
+    __shared__ __attribute__((aligned(16))) unsigned char As[PLANES][TM_ * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[PLANES][TN_ * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, khalf = lane >> 5;
+    const int tiles_n = N / TN_;
+    const int m0 = (blockIdx.x / tiles_n) * TM_, n0 = (blockIdx.x % tiles_n) * TN_;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[4], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * 512, row = c >> 3, kc = c & 7;
+            ra[i] = *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + row) * K + k0 + kc * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * 512, row = c >> 3, kc = c & 7;
+            rb[i] = *reinterpret_cast<const f32x4*>(B + (size_t)(n0 + row) * K + k0 + kc * 4);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * 512, row = c >> 3, kc = c & 7;
+            const int off = row * 64 + ((((kc >> 1) ^ ((row >> 1) & 3)) << 4) | ((kc & 1) << 3));
+            u32x2 pa[PLANES];
+            split4<PLANES>(ra[i], pa);
+#pragma unroll
+            for (int p = 0; p < PLANES; ++p) *reinterpret_cast<u32x2*>(&As[p][off]) = pa[p];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * 512, row = c >> 3, kc = c & 7;
+            const int off = row * 64 + ((((kc >> 1) ^ ((row >> 1) & 3)) << 4) | ((kc & 1) << 3));
+            u32x2 pb[PLANES];
+            split4<PLANES>(rb[i], pb);
+#pragma unroll
+            for (int p = 0; p < PLANES; ++p) *reinterpret_cast<u32x2*>(&Bs[p][off]) = pb[p];
+        }
+    };
+    const int nk = K / BK;
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        stage();
+        __syncthreads();
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            bf16x8 a[2][PLANES], b[2][PLANES];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32 + l31;
+                const int off = row * 64 + (((2 * q + khalf) ^ ((row >> 1) & 3)) << 4);
+#pragma unroll
+                for (int p = 0; p < PLANES; ++p) a[i][p] = *reinterpret_cast<const bf16x8*>(&As[p][off]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn * 64 + j * 32 + l31;
+                const int off = row * 64 + (((2 * q + khalf) ^ ((row >> 1) & 3)) << 4);
+#pragma unroll
+                for (int p = 0; p < PLANES; ++p) b[j][p] = *reinterpret_cast<const bf16x8*>(&Bs[p][off]);
+            }
+#pragma unroll
+            for (int s = (PLANES == 3 ? 2 : PLANES - 1); s >= 0; --s) {
+#pragma unroll
+                for (int pa = 0; pa < PLANES; ++pa) {
+                    const int pb = s - pa;
+                    if (pb < 0 || pb >= PLANES) continue;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const int col = n0 + wn * 64 + j * 32 + l31;
+                C[(size_t)row * N + col] = acc[i][j][r];
+            }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 template <int PLANES, int ABL = 0>
@@ -253,9 +356,10 @@ void run(int M, int N, int K, bool check) {
     CK(hipMalloc(&dA, ha.size() * 4)); CK(hipMalloc(&dB, hb.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4));
     CK(hipMemcpy(dA, ha.data(), ha.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dB, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
-    dim3 grid((M / BM) * (N / BN)), block(256);
+    dim3 grid(ABL == 8 ? (M / 256) * (N / 128) : (M / BM) * (N / BN)), block(ABL == 8 ? 512 : 256);
     if (ABL == 9) hipLaunchKernelGGL((gemm_split_db_kernel<PLANES>), grid, block, 0, 0, dA, dB, dC, M, N, K);
-    else hipLaunchKernelGGL((gemm_split_kernel<PLANES, ABL == 9 ? 0 : ABL>), grid, block, 0, 0, dA, dB, dC, M, N, K);
+    else if (ABL == 8) hipLaunchKernelGGL((gemm_split_256_kernel<PLANES>), grid, block, 0, 0, dA, dB, dC, M, N, K);
+    else hipLaunchKernelGGL((gemm_split_kernel<PLANES, (ABL >= 8) ? 0 : ABL>), grid, block, 0, 0, dA, dB, dC, M, N, K);
     CK(hipDeviceSynchronize());
     if (check) {
         std::vector<float> hc((size_t)M * N);
@@ -276,7 +380,8 @@ void run(int M, int N, int K, bool check) {
         CK(hipEventRecord(e0));
         for (int r = 0; r < reps; ++r) {
             if (ABL == 9) hipLaunchKernelGGL((gemm_split_db_kernel<PLANES>), grid, block, 0, 0, dA, dB, dC, M, N, K);
-            else hipLaunchKernelGGL((gemm_split_kernel<PLANES, ABL == 9 ? 0 : ABL>), grid, block, 0, 0, dA, dB, dC, M, N, K);
+            else if (ABL == 8) hipLaunchKernelGGL((gemm_split_256_kernel<PLANES>), grid, block, 0, 0, dA, dB, dC, M, N, K);
+            else hipLaunchKernelGGL((gemm_split_kernel<PLANES, (ABL >= 8) ? 0 : ABL>), grid, block, 0, 0, dA, dB, dC, M, N, K);
         }
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
@@ -294,15 +399,16 @@ int main() {
     run<2>(256, 256, 128, true);
     run<3>(384, 128, 2048, true);
     run<3, 9>(384, 128, 2048, true);
+    run<3, 8>(512, 256, 256, true);
     run<2, 9>(256, 256, 128, true);
     const int shapes[][3] = {{11520, 2048, 512}, {11520, 512, 2048}, {11520, 1536, 512}, {11520, 512, 512}, {12288, 4096, 4096}};
     for (auto& sh : shapes) {
         run<3>(sh[0], sh[1], sh[2], false);
         run<2>(sh[0], sh[1], sh[2], false);
         run<1>(sh[0], sh[1], sh[2], false);
-        run<3, 9>(sh[0], sh[1], sh[2], false);
-        run<2, 9>(sh[0], sh[1], sh[2], false);
-        run<1, 9>(sh[0], sh[1], sh[2], false);
+        run<3, 8>(sh[0], sh[1], sh[2], false);
+        run<2, 8>(sh[0], sh[1], sh[2], false);
+        run<1, 8>(sh[0], sh[1], sh[2], false);
     }
     if (getenv("ABLATE")) {
         run<3, 1>(12288, 4096, 4096, false); run<3, 2>(12288, 4096, 4096, false); run<3, 3>(12288, 4096, 4096, false);
