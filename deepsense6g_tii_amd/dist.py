@@ -50,10 +50,14 @@ class GradReducer:
     when grad_flat[lo:hi] is final (milestones arrive in increasing offset order).  `finish()` flushes
     the tail and makes the current stream wait for every outstanding all-reduce."""
 
-    def __init__(self, grad_flat, group=None, min_bucket_elems=8 << 20):
+    def __init__(self, grad_flat, group=None, min_bucket_elems=8 << 20, flush_at=None):
         self.g = grad_flat
         self.group = group
         self.min_bucket = int(min_bucket_elems)
+        # milestone after which whatever has accumulated is sent at once: the bucket that is still open when the backward
+        # walk ends cannot overlap anything, so it should hold as little as possible (attach(): everything up to the first
+        # GPT stage goes out while layer1 / the stems are still being differentiated; only their ~0.6 M gradients remain)
+        self.flush_at = flush_at
         self.works = []
         self.lo = 0
         self.hi = 0
@@ -70,7 +74,7 @@ class GradReducer:
     def ready(self, k, lo, hi):
         assert lo == self.hi, "gradient milestones must arrive as a contiguous, growing prefix"
         self.hi = hi
-        if self.hi - self.lo >= self.min_bucket:
+        if self.hi - self.lo >= self.min_bucket or (self.flush_at is not None and k == self.flush_at):
             self._flush()
 
     def _flush(self):
@@ -100,7 +104,7 @@ def broadcast_parameters(model, src=0, group=None):
 
 def attach(model, optimizer, group=None, min_bucket_elems=8 << 20):
     """Wire a GradReducer into the model's backward walk and fold the 1/world average into the optimizer."""
-    red = GradReducer(model.flat_parameters()[1], group, min_bucket_elems)
+    red = GradReducer(model.flat_parameters()[1], group, min_bucket_elems, flush_at=7)  # 7 = transformer1 (model._milestone)
     model.grad_ready_hook = red.ready
     optimizer.grad_scale = 1.0 / red.world
     return red

@@ -167,3 +167,21 @@ def test_checkpoint_prefix_and_csv(tmp_path):
     lines = out.read_text().strip().split("\n")
     assert lines[0] == "index,top-1 beam,top-2 beam,top-3 beam"   # train2_seq.py:343-346 (1-based beams)
     assert lines[1] == "0,5,4,51" and lines[2] == "1,64,1,2"
+
+
+def test_grad_reducer_flushes_early_at_the_given_milestone():
+    """flush_at: the bucket open at that milestone goes out even below the size threshold, so the last (unoverlappable)
+    bucket only holds what comes after it."""
+    import torch
+    from deepsense6g_tii_amd import dist as ddist
+    g = torch.zeros(100)
+    red = ddist.GradReducer(g, min_bucket_elems=1000, flush_at=2)
+    red.begin()
+    red.ready(0, 0, 10)
+    red.ready(1, 10, 30)
+    assert red.issued == []
+    red.ready(2, 30, 60)
+    assert red.issued == [(0, 60)]
+    red.ready(3, 60, 90)
+    red.finish()
+    assert red.issued == [(0, 60), (60, 90)]
