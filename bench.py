@@ -11,12 +11,15 @@ sequence, bs=12 per GPU); configs[1] ("image-only") is the same compute with zer
  and configs[0] is the CPU plumbing case timed here as `cpu_baseline`.
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline     : dominant kernel = the implicit-GEMM instantiation with the largest share of step time;
-                 achieved = algorithmic FLOPs of its launches / their HIP-event time, measured live in one
-                 extra instrumented step (single stream, so brackets are not inflated by the concurrent trunk
-                 streams of the timed region); peak = 157.3 TFLOP/s (fp32 MFMA, gfx950); traffic = HBM bytes per
-                 launch from the committed PMC passes (profiles/r01_pmc_traffic.json)
-  cpu_baseline : the CPU oracle (oracle/, torch fp32 on the host cores) timed on a bounded sample.
+  roofline     : dominant kernel = the matrix-core kernel with the largest share of step time; achieved = the MFMA
+                 FLOPs its launches EXECUTE / their HIP-event time, measured live in one extra instrumented step
+                 (single stream, so brackets are not inflated by the concurrent trunk streams of the timed region);
+                 frac = achieved / peak (157.3 TFLOP/s fp32 MFMA, gfx950) - a Winograd kernel executes 2.25x fewer
+                 FLOPs than the direct 3x3 conv it replaces, its algorithmic rate is the separate key
+                 `algorithmic_tflops`; step_frac = whole-step algorithmic rate / peak; traffic = HBM bytes per launch
+                 from the committed PMC passes (profiles/r0N_pmc_traffic.json)
+  cpu_baseline : the CPU oracle (oracle/, torch fp32 on the host cores): bs=2 (3 warm-up + 10 timed) and bs=12
+                 (1 warm-up + 3 timed) steps of fwd + focal + bwd + AdamW, median step time, CPU model and threads.
 """
 from __future__ import annotations
 
@@ -52,30 +55,125 @@ def host_threads():
     return max(1, min(n, quota))
 
 
-def cpu_baseline(batch, steps):
-    """fwd + focal + bwd + AdamW of the CPU oracle on the host cores (reference CPU path restated)."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(batch=12, steps=3, warmup=1, small_batch=2, small_steps=10, small_warmup=3):
+    """fwd + focal + bwd + AdamW of the CPU oracle on the host cores (reference CPU path restated), SURVEY 8(d)
+    protocol: all threads of the job's cgroup share, fp32, median step time at bs=2 (BASELINE configs[0]) and at the
+    benchmark's bs=12.  `value` = the bs=12 rate (the same workload the GPU line measures)."""
+    import statistics
+
     from oracle import fusion_ref as fr
     from oracle import train_ref as tr
     cores = host_threads()
     torch.set_num_threads(cores)
     cfg = fr.RefConfig()
-    sd = fr.make_state(cfg, seed=0, scheme="init")
-    params = [v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not fr.is_buffer(k)]
-    opt = torch.optim.AdamW(params, lr=1e-4)
-    imgs, lids, rads, gps, target, _ = fr.make_inputs(cfg, batch, seed=100)
-    times = []
-    for it in range(steps + 1):
-        t0 = time.perf_counter()
-        opt.zero_grad(set_to_none=True)
-        logits = fr.transfuser_forward(sd, imgs, lids, rads, gps, cfg, fr.Ctx(training=True, dropout=True))
-        loss = tr.sigmoid_focal_loss(logits, target)
-        loss.backward()
-        opt.step()
-        times.append(time.perf_counter() - t0)
-    timed = times[1:]
-    return dict(value=batch * len(timed) / sum(timed), unit="samples/s", cores=cores, kind="port",
-                sample=f"{len(timed)} timed steps (+1 warm-up) of bs={batch}, fp32, torch {torch.__version__} CPU, "
-                       f"oracle/fusion_ref.py fwd+focal+bwd+AdamW")
+
+    def run(bs, n_warm, n_timed):
+        sd = fr.make_state(cfg, seed=0, scheme="init")
+        params = [v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not fr.is_buffer(k)]
+        opt = torch.optim.AdamW(params, lr=1e-4)
+        imgs, lids, rads, gps, target, _ = fr.make_inputs(cfg, bs, seed=100)
+        times = []
+        for it in range(n_warm + n_timed):
+            t0 = time.perf_counter()
+            opt.zero_grad(set_to_none=True)
+            logits = fr.transfuser_forward(sd, imgs, lids, rads, gps, cfg, fr.Ctx(training=True, dropout=True))
+            loss = tr.sigmoid_focal_loss(logits, target)
+            loss.backward()
+            opt.step()
+            times.append(time.perf_counter() - t0)
+        timed = times[n_warm:]
+        return bs / statistics.median(timed), timed
+
+    small, small_t = run(small_batch, small_warmup, small_steps) if small_steps > 0 else (None, [])
+    big, big_t = run(batch, warmup, steps)
+    return dict(value=big, unit="samples/s", cores=cores, kind="port", cpu_model=cpu_model_name(),
+                sample=f"median of {len(big_t)} timed steps (+{warmup} warm-up) of bs={batch}; bs={small_batch}: median of "
+                       f"{len(small_t)} (+{small_warmup} warm-up); fp32, torch {torch.__version__} CPU, "
+                       f"oracle/fusion_ref.py fwd+focal+bwd+AdamW, {cores} threads",
+                by_batch={str(batch): dict(samples_per_s=big, step_s=[round(t, 3) for t in big_t]),
+                          **({str(small_batch): dict(samples_per_s=small, step_s=[round(t, 3) for t in small_t])}
+                             if small is not None else {})})
+
+
+def variant_name(v, dtype="f32", short=False):
+    """variant code (include/ds6g.h): 10000 * wide + 1000 * epilogue + 100 * uniform-walk + 10 * mode + tile  ->  the
+    template instantiation exactly as rocprofv3 names it: igemm_kernel<mode, BM, BN, epilogue, BK, bf16, walk>"""
+    if v >= 20000:  # winograd.hip (flops recorded = those of the direct 3x3 conv it replaces)
+        return ("winograd_fwd_kernel<1>", "winograd_wgrad_kernel")[v - 20000] if not short else \
+            ("winograd/fwd+dgrad", "winograd/wgrad")[v - 20000]
+    bfm = ("f32", "bf16", "f32x3", "f32x6").index(dtype)
+    wide, epi, walk, mode, tile = v // 10000, v % 10000 // 1000, v % 1000 // 100, v % 100 // 10, v % 10
+    bm, bn = VARIANT_NAMES[tile].split("x")
+    if short:
+        return (f"{MODE_NAMES[mode]}/{bm}x{bn}" + ("/k32" if wide else "") + ("/epi" if epi else "") +
+                ("" if walk else "/general-walk"))
+    return f"igemm_kernel<{mode}, {bm}, {bn}, {epi}, {32 if wide else 16}, {bfm}, {walk}>"
+
+
+def peak_tflops_for(dtype):
+    # f32x3 executes three bf16 MFMA flops per algorithmic flop: its ceiling in algorithmic flops is a third of the bf16 peak
+    return {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32x3": PEAK_BF16_MFMA_TFLOPS / 3,
+            "f32x6": PEAK_BF16_MFMA_TFLOPS / 6}[dtype]
+
+
+WINOGRAD_EXEC = 1.0 / 2.25   # F(2x2,3x3): 16 multiplies per 2x2 output tile and channel pair instead of 36
+
+
+def roofline_from_records(agg, dtype, traffic):
+    """agg: {variant: [launches, algorithmic flops, ms]} of ONE instrumented step.  The roofline kernel is the matrix-core
+    kernel with the largest share of step time.  `achieved` / `frac` are the MFMA FLOPs the kernel EXECUTES per second
+    (a fraction of the matrix peak, <= 1 by construction); a Winograd kernel's rate in direct-conv FLOPs (SURVEY 8d counts
+    a 3x3 conv as 9 taps) is reported separately as `algorithmic_tflops`."""
+    peak = peak_tflops_for(dtype)
+    dom = max(agg, key=lambda v: agg[v][2])
+
+    def one(v):
+        cnt, fl, ms = agg[v]
+        ex = WINOGRAD_EXEC if v >= 20000 else 1.0
+        algo = fl / (ms * 1e-3) / 1e12
+        return dict(kernel=variant_name(v, dtype), achieved=algo * ex, peak=peak, unit="TFLOP/s", frac=algo * ex / peak,
+                    traffic=traffic(v) if dtype == "f32" else None, algorithmic_tflops=algo, launches_per_step=cnt,
+                    avg_launch_us=ms * 1e3 / cnt, flops_per_launch=fl * ex / cnt, algorithmic_flops_per_launch=fl / cnt)
+
+    roof = dict(bound="mfma", **one(dom))
+    if dom >= 20000:
+        roof["note"] = ("Winograd F(2x2,3x3): achieved / frac count the MFMA flops the kernel executes (2.25x fewer than the "
+                        "direct 3x3 conv); algorithmic_tflops is the direct-conv rate, see DESIGN.md 3.1b")
+        direct = [v for v in agg if v < 20000]
+        if direct:
+            d = one(max(direct, key=lambda v: agg[v][2]))
+            d.pop("peak"), d.pop("unit")
+            roof["largest_direct_kernel"] = d
+    tot_ms = sum(v[2] for v in agg.values())
+    tot_fl = sum(v[1] for v in agg.values())
+    tot_ex = sum(v[1] * (WINOGRAD_EXEC if k >= 20000 else 1.0) for k, v in agg.items())
+    roof["igemm_family"] = dict(achieved=tot_ex / (tot_ms * 1e-3) / 1e12, algorithmic_tflops=tot_fl / (tot_ms * 1e-3) / 1e12,
+                                ms_per_step=tot_ms, flops_per_step=tot_fl,
+                                by_variant={variant_name(v, dtype, short=True):
+                                            dict(launches=a[0], ms=round(a[2], 3),
+                                                 tflops=round(a[1] * (WINOGRAD_EXEC if v >= 20000 else 1.0) / (a[2] * 1e-3) / 1e12, 2))
+                                            for v, a in sorted(agg.items())})
+    return roof
+
+
+def pmc_traffic_table():
+    """HBM bytes per launch by kernel name from the committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and WRITE_SIZE
+    are collected in separate runs of this same command, so bench.py cannot measure them live; {} when absent."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
+        if os.path.exists(path):
+            return {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(path))["kernels"].items()}
+    return {}
 
 
 class IgemmTimer:
@@ -104,9 +202,6 @@ class IgemmTimer:
             d[2] += ms[i]
         return agg
 
-    def uninstall(self):
-        pass
-
 
 def main():
     ap = argparse.ArgumentParser()
@@ -128,7 +223,8 @@ def main():
                     help="run the three trunks on one stream (per-kernel profiling: durations are not overlapped)")
     ap.add_argument("--debug-flags", type=lambda v: int(v, 0), default=0, help="ds6g_set_debug_flags (tuning experiments)")
     ap.add_argument("--cpu-batch", type=int, default=12)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps at --cpu-batch (after 1 warm-up)")
+    ap.add_argument("--cpu-small-steps", type=int, default=10, help="timed CPU-oracle steps at bs=2 (after 3 warm-up); 0 = skip")
     args = ap.parse_args()
 
     from deepsense6g_tii_amd import dist as ddist
@@ -137,16 +233,16 @@ def main():
     from deepsense6g_tii_amd.synthetic import make_batch
     from deepsense6g_tii_amd.train import EMA, FusedAdamW, train_iteration
 
-    ops.set_compute_mode(args.dtype)
-    if args.debug_flags:
-        from deepsense6g_tii_amd._lib import lib
-        lib().set_debug_flags(args.debug_flags)
-    # f32x3 executes three bf16 MFMA flops per algorithmic flop: its ceiling in algorithmic flops is a third of the bf16 peak
-    peak_tflops = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32x3": PEAK_BF16_MFMA_TFLOPS / 3, "f32x6": PEAK_BF16_MFMA_TFLOPS / 6}[args.dtype]
+    # the process group first: under torch.distributed.run nothing may touch the GPU before init_process_group
     rank, world, local = ddist.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    ops.set_compute_mode(args.dtype)
+    if args.debug_flags:
+        from deepsense6g_tii_amd._lib import lib
+        lib().set_debug_flags(args.debug_flags)
+    peak_tflops = peak_tflops_for(args.dtype)
 
     cfg = GlobalConfig()
     torch.manual_seed(100)  # reference seeds everything with 100 (train2_seq.py:430-437)
@@ -198,60 +294,10 @@ def main():
         train_iteration(model, opt, batch, ema, reducer)
         agg = timer.summary()
     finally:
-        timer.uninstall()
         model.multi_stream = ms_flag
-    def pmc_traffic(variant):
-        """HBM bytes per launch of an igemm instantiation from the committed rocprofv3 PMC passes (profiles/):
-        FETCH_SIZE and WRITE_SIZE are collected in separate runs of this same command, so bench.py cannot measure
-        them live; null when the summary is absent."""
-        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if not os.path.exists(path):
-            return None
-        ks = json.load(open(path))["kernels"]
-        v = ks.get(vname(variant))
-        return v["hbm_bytes_per_launch"] if v else None
-
-    def vname(v, short=False):
-        # variant code (include/ds6g.h): 10000 * wide + 1000 * epilogue + 100 * uniform-walk + 10 * mode + tile  ->  the template
-        # instantiation exactly as rocprofv3 names it: igemm_kernel<mode, BM, BN, epilogue, BK, bf16, walk>
-        if v >= 20000:  # winograd.hip (flops recorded = those of the direct 3x3 conv it replaces)
-            return ("winograd_fwd_kernel<1>", "winograd_wgrad_kernel")[v - 20000] if not short else \
-                ("winograd/fwd+dgrad", "winograd/wgrad")[v - 20000]
-        bfm = ("f32", "bf16", "f32x3", "f32x6").index(args.dtype)
-        wide, epi, walk, mode, tile = v // 10000, v % 10000 // 1000, v % 1000 // 100, v % 100 // 10, v % 10
-        bm, bn = VARIANT_NAMES[tile].split("x")
-        if short:
-            return (f"{MODE_NAMES[mode]}/{bm}x{bn}" + ("/k32" if wide else "") + ("/epi" if epi else "") +
-                    ("" if walk else "/general-walk"))
-        return f"igemm_kernel<{mode}, {bm}, {bn}, {epi}, {32 if wide else 16}, {bfm}, {walk}>"
-
     if agg:
-        # the roofline kernel is the matrix-core kernel with the largest share of step time.  `achieved` follows the
-        # contract: ALGORITHMIC flops (SURVEY 8d counts a 3x3 conv as 9 taps) / kernel time.  A Winograd kernel executes
-        # 2.25x fewer matrix FLOPs than that, so its algorithmic rate can exceed the fp32 MFMA peak; `executed_tflops`
-        # (what the matrix pipe actually does) is reported next to it, and so is the largest direct instantiation.
-        dom = max(agg, key=lambda v: agg[v][2])
-        cnt, fl, ms = agg[dom]
-        tot_ms = sum(v[2] for v in agg.values())
-        tot_fl = sum(v[1] for v in agg.values())
-        exec_scale = (1.0 / 2.25) if dom >= 20000 else 1.0
-        roof = dict(bound="mfma", kernel=vname(dom),
-                    achieved=fl / (ms * 1e-3) / 1e12, peak=peak_tflops, unit="TFLOP/s",
-                    frac=fl / (ms * 1e-3) / 1e12 / peak_tflops, traffic=pmc_traffic(dom) if args.dtype == "f32" else None,
-                    executed_tflops=fl * exec_scale / (ms * 1e-3) / 1e12,
-                    launches_per_step=cnt, avg_launch_us=ms * 1e3 / cnt, flops_per_launch=fl / cnt)
-        if dom >= 20000:
-            roof["note"] = ("Winograd F(2x2,3x3): algorithmic (direct-conv) flops / time; the kernel executes 2.25x fewer "
-                            "MFMA flops (executed_tflops), see DESIGN.md 3.1b")
-            d2 = max((v for v in agg if v < 20000), key=lambda v: agg[v][2])
-            c2, f2, m2 = agg[d2]
-            roof["largest_direct_kernel"] = dict(kernel=vname(d2), achieved=f2 / (m2 * 1e-3) / 1e12,
-                                                 frac=f2 / (m2 * 1e-3) / 1e12 / peak_tflops, launches_per_step=c2,
-                                                 avg_launch_us=m2 * 1e3 / c2, traffic=pmc_traffic(d2) if args.dtype == "f32" else None)
-        roof["igemm_family"] = dict(achieved=tot_fl / (tot_ms * 1e-3) / 1e12, ms_per_step=tot_ms, flops_per_step=tot_fl,
-                                    by_variant={vname(v, short=True): dict(launches=a[0], ms=round(a[2], 3),
-                                                                           tflops=round(a[1] / (a[2] * 1e-3) / 1e12, 2))
-                                                for v, a in sorted(agg.items())})
+        table = pmc_traffic_table()
+        roof = roofline_from_records(agg, args.dtype, lambda v: table.get(variant_name(v, args.dtype)))
 
     # ---- the split-bf16 matrix-core modes next to the exact one (same model / batch / timing protocol; reported beside
     # `value`, never as it) ----
@@ -295,7 +341,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_batch, args.cpu_steps)
+        cpu = cpu_baseline(args.cpu_batch, args.cpu_steps, 1, 2, args.cpu_small_steps, 3)
 
     if rank == 0:
         samples = args.batch * world * args.steps
@@ -322,6 +368,7 @@ def main():
             "loss": final_loss,
             "algorithmic_gflop_per_sample": 559.3,
             "model_tflops": value * 559.3e9 / 1e12,
+            "step_frac": value / world * 559.3e9 / 1e12 / peak_tflops,   # per-GPU algorithmic rate / matrix peak of the dtype
             "roofline": roof,
             "cpu_baseline": cpu,
             "other_modes": alt,

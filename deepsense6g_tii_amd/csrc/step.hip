@@ -44,9 +44,52 @@ struct AdamArgs {
     float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, ema_decay, grad_scale;
 };
 
+// sum of squares of n4*4 floats: per-block double partials, the LAST block to finish (device-scope counter) adds them in
+// index order (deterministic) and writes out[0] = ||g||_2, out[1] = min(1, max_norm / (||g||_2 + 1e-6)) - the
+// clip coefficient of torch.nn.utils.clip_grad_norm_ (train2_seq_30to5.py:120), applied by adamw_kernel through
+// grad_scale_dev so the gradient arena is not rewritten.  ws: [0] = counter (zero on entry, re-zeroed on exit), doubles
+// from byte 8 on.
+__global__ __launch_bounds__(256) void grad_norm_kernel(const float* __restrict__ g, long n4, float max_norm,
+                                                        float pre_scale, float* __restrict__ out,
+                                                        unsigned* __restrict__ counter, double* __restrict__ partial) {
+    __shared__ double red[4];
+    __shared__ bool last;
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(g + i * 4);
+        acc += (double)(v[0] * v[0] + v[1] * v[1]) + (double)(v[2] * v[2] + v[3] * v[3]);
+    }
+    acc = wave_reduce_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        __threadfence();
+        last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    double tot = 0.0;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) tot += __builtin_nontemporal_load(partial + i);
+    tot = wave_reduce_sum_d(tot);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3])) * pre_scale;
+        out[0] = norm;
+        const float coef = max_norm / (norm + 1e-6f);
+        out[1] = coef < 1.f ? coef : 1.f;
+        *counter = 0u;
+    }
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
-                                                    float* __restrict__ shadow, long n4, AdamArgs a) {
+                                                    float* __restrict__ shadow, long n4, AdamArgs a,
+                                                    const float* __restrict__ grad_scale_dev) {
+    if (grad_scale_dev) a.grad_scale *= *grad_scale_dev;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         f32x4 pv = *reinterpret_cast<f32x4*>(p + i * 4);
         const f32x4 gv = a.grad_scale * *reinterpret_cast<const f32x4*>(g + i * 4);
@@ -159,7 +202,8 @@ int ds6g_focal_loss(const float* logits, const float* target, float* loss, float
 // scaling) over n contiguous floats; step is 1-based.  grad_scale multiplies g first (1/world for DP).
 // shadow != NULL also does the EMA update shadow = (1-d) p_new + d shadow.
 int ds6g_adamw_step(float* p, const float* g, float* m, float* v, float* shadow, long n, int step, float lr,
-                    float beta1, float beta2, float eps, float wd, float ema_decay, float grad_scale, void* stream) {
+                    float beta1, float beta2, float eps, float wd, float ema_decay, float grad_scale,
+                    const float* grad_scale_dev, void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(p && g && m && v && n % 4 == 0 && step >= 1);
     AdamArgs a;
@@ -169,7 +213,25 @@ int ds6g_adamw_step(float* p, const float* g, float* m, float* v, float* shadow,
     a.ema_decay = ema_decay; a.grad_scale = grad_scale;
     const long n4 = n / 4;
     const int grid = (int)(n4 + 255) / 256 < 4096 ? (int)((n4 + 255) / 256) : 4096;
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, shadow, n4, a);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, shadow, n4, a,
+                       grad_scale_dev);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+// out[0] = pre_scale * ||g||_2 over n floats, out[1] = min(1, max_norm / (out[0] + 1e-6)): the global-norm clip of
+// torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) on the flat gradient arena (pre_scale = 1/world when the
+// arena holds a rank SUM).  Pass out + 1 as ds6g_adamw_step's grad_scale_dev.  ws: >= 8 + 8 * 1024 bytes, first 4 bytes
+// zero on first use (the kernel leaves them zero).
+int ds6g_grad_norm_clip(const float* g, long n, float max_norm, float pre_scale, float* out, void* ws, size_t ws_bytes,
+                        void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(g && out && ws && n > 0 && n % 4 == 0 && max_norm > 0.f);
+    const long n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+    if (ws_bytes < 8 + 8 * (size_t)grid) return DS6G_ERR_WORKSPACE;
+    hipLaunchKernelGGL(grad_norm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n4, max_norm, pre_scale, out,
+                       (unsigned*)ws, (double*)((char*)ws + 8));
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }

@@ -105,6 +105,9 @@ def broadcast_parameters(model, src=0, group=None):
 def attach(model, optimizer, group=None, min_bucket_elems=8 << 20):
     """Wire a GradReducer into the model's backward walk and fold the 1/world average into the optimizer."""
     red = GradReducer(model.flat_parameters()[1], group, min_bucket_elems, flush_at=7)  # 7 = transformer1 (model._milestone)
-    model.grad_ready_hook = red.ready
+    model.grad_ready_hook = red.ready  # TransFuser._begin_backward calls red.begin() itself (autograd path included)
     optimizer.grad_scale = 1.0 / red.world
+    # independent dropout masks per rank, as DataParallel replicas draw from their own device RNG
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    model.set_dropout_seed(model._seed, rank)
     return red

@@ -403,6 +403,17 @@ class TransFuser(nn.Module):
         # .grad is None -> write fresh and attach the arena view; .grad is our view -> accumulate in
         # place (torch semantics when zero_grad was not called); foreign tensor -> write, then add.
         self._gmode, self._fresh, self._foreign = {}, [], []
+        if self.grad_ready_hook is not None:
+            # data parallel: a bucket is all-reduced in place the moment it is final, so every gradient must be written
+            # fresh this step - accumulating into an already-reduced arena would sum the earlier steps world times over
+            bad = [n for n, p in self.named_parameters() if p.grad is not None]
+            if bad:
+                raise RuntimeError(f"data-parallel backward needs zero_grad(set_to_none=True) first; {len(bad)} parameters "
+                                   f"still hold a gradient (e.g. {bad[0]}): gradient accumulation across steps is not "
+                                   "supported with the overlapped all-reduce")
+            begin = getattr(self.grad_ready_hook, "__self__", None)
+            if begin is not None and hasattr(begin, "begin"):
+                begin.begin()
         for name, p in self.named_parameters():
             gv = self._gview[name]
             if p.grad is None:
@@ -420,11 +431,31 @@ class TransFuser(nn.Module):
             self.grad_ready_hook(k, lo, self._milestone_end[k])
 
     def _end_backward(self):
+        owner = getattr(self.grad_ready_hook, "__self__", None)
+        if owner is not None and hasattr(owner, "finish"):
+            owner.finish()  # flush the tail bucket; the calling stream waits for every outstanding all-reduce
         for p, gv in self._fresh:
             p.grad = gv
         for p, gv in self._foreign:
             p.grad.add_(gv)
         self._gmode, self._fresh, self._foreign = {}, [], []
+
+    def set_dropout_seed(self, seed, rank=0):
+        """Seed of the counter-based dropout masks.  Data-parallel ranks must draw independent masks (the reference's
+        DataParallel replicas each use their own device RNG): the rank is mixed in with a splitmix64 finalizer."""
+        z = (int(seed) + 0x9E3779B97F4A7C15 * (int(rank) + 1)) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        self._seed = (z ^ (z >> 31)) if rank else int(seed) & 0xFFFFFFFFFFFFFFFF
+        return self._seed
+
+    def rng_state(self):
+        """(seed, counter) of the dropout stream - saved with the optimizer state so a resumed run continues the mask
+        sequence instead of replaying it from step 0."""
+        return dict(seed=int(self._seed), counter=int(self._drop_counter))
+
+    def set_rng_state(self, st):
+        self._seed, self._drop_counter = int(st["seed"]), int(st["counter"])
 
     def _next_drop(self, numel):
         off = self._drop_counter
@@ -493,8 +524,12 @@ class TransFuser(nn.Module):
         """Fused forward -> sigmoid focal loss -> backward without autograd (the harness path).
         Returns (loss tensor [1], logits)."""
         images, lidars, radars, gps = self._inputs(image_list, lidar_list, radar_list, gps)
+        if target.dim() == 1:  # class-index target (temp_coef = 0 path, train2_seq.py:124 -> FocalLoss :297-298)
+            target = torch.nn.functional.one_hot(target.long(), num_classes=64)
         target = target.to(self.device, F32).contiguous()
         logits, tape = self._run_forward(images, lidars, radars, gps, record=True)
+        if tuple(target.shape) != tuple(logits.shape):  # the kernel reads logits.numel() floats from both buffers
+            raise ValueError(f"focal-loss target shape {tuple(target.shape)} != logits shape {tuple(logits.shape)}")
         loss = torch.empty(1, dtype=F32, device=self.device)
         dlogits = torch.empty_like(logits)
         lib().focal_loss(logits.data_ptr(), target.data_ptr(), loss.data_ptr(), dlogits.data_ptr(), logits.numel(),
@@ -725,6 +760,8 @@ class TransFuser(nn.Module):
             stem_ctx.append(c)
         cap = getattr(self, "_capture", None)  # test hook: name -> list of NHWC / token tensors
         if cap is not None:
+            if streams is not None:
+                self._join()  # the stems ran on the trunk streams; the clone below is on the calling stream
             cap["stem"] = [f.clone() for f in feats]
         layer_ctx, stage_ctx = [], []
         gps_src = (gps, gps.data_ptr(), 2 * B, 0, 2)

@@ -24,6 +24,9 @@ class _FocalFn(torch.autograd.Function):
     def forward(ctx, logits, target, alpha, gamma):
         logits = logits.contiguous()
         target = target.contiguous()
+        if tuple(target.shape) != tuple(logits.shape) or target.dtype != F32 or target.device != logits.device:
+            raise ValueError(f"focal-loss target {tuple(target.shape)}/{target.dtype} does not match logits "
+                             f"{tuple(logits.shape)}/fp32 (the kernel reads logits.numel() floats from both)")
         loss = torch.empty(1, dtype=F32, device=logits.device)
         dlogits = torch.empty_like(logits)
         lib().focal_loss(logits.data_ptr(), target.data_ptr(), loss.data_ptr(), dlogits.data_ptr(), logits.numel(),
@@ -64,8 +67,16 @@ class FusedAdamW:
     weight_decay .01 on every parameter) as ONE streaming kernel over the parameter arena, optionally
     fused with the EMA shadow update (train2_seq.py:315-320)."""
 
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, ema_decay=None):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, ema_decay=None,
+                 max_grad_norm=None):
+        """max_grad_norm: torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) of the 30->5 training step
+        (train2_seq_30to5.py:120, max_norm 3.0) folded into the step: one reduction over the gradient arena, the clip
+        coefficient stays on the device and is multiplied into the AdamW kernel's gradient scale (no host sync, the
+        arena is not rewritten)."""
         self.model = model
+        self.max_grad_norm = max_grad_norm
+        self._clip_out = torch.zeros(2, dtype=F32, device=model.device)           # [total norm, clip coefficient]
+        self._clip_ws = torch.zeros(8 + 8 * 1024, dtype=torch.uint8, device=model.device)
         p, g = model.flat_parameters()
         self.m = torch.zeros_like(p)
         self.v = torch.zeros_like(p)
@@ -88,14 +99,24 @@ class FusedAdamW:
         p, g = self.model.flat_parameters()
         self.step_count += 1
         grp = self.param_groups[0]
+        coef = 0
+        if self.max_grad_norm is not None:
+            lib().grad_norm_clip(g.data_ptr(), g.numel(), float(self.max_grad_norm), float(self.grad_scale),
+                                 self._clip_out.data_ptr(), self._clip_ws.data_ptr(), self._clip_ws.numel(), ops._stream())
+            coef = self._clip_out.data_ptr() + 4
         lib().adamw_step(p.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                          0 if self.shadow is None else self.shadow.data_ptr(), p.numel(), self.step_count,
                          float(grp["lr"]), grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"],
-                         0.0 if self.ema_decay is None else float(self.ema_decay), float(self.grad_scale),
+                         0.0 if self.ema_decay is None else float(self.ema_decay), float(self.grad_scale), coef,
                          ops._stream())
 
+    def last_grad_norm(self):
+        """total gradient norm of the last clipped step (host read: synchronises)"""
+        return float(self._clip_out[0].item())
+
     def state_dict(self):
-        return dict(m=self.m, v=self.v, step=self.step_count, shadow=self.shadow, param_groups=self.param_groups)
+        return dict(m=self.m, v=self.v, step=self.step_count, shadow=self.shadow, param_groups=self.param_groups,
+                    dropout_rng=self.model.rng_state())
 
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"])
@@ -103,6 +124,8 @@ class FusedAdamW:
         self.step_count = int(sd["step"])
         if self.shadow is not None and sd.get("shadow") is not None:
             self.shadow.copy_(sd["shadow"])
+        if sd.get("dropout_rng") is not None:  # resume the mask sequence, do not replay it from step 0
+            self.model.set_rng_state(sd["dropout_rng"])
 
 
 class EMA:
@@ -211,25 +234,76 @@ def strip_module_prefix(state_dict):
     return {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
 
 
+SCENARIOS = ("scenario31", "scenario32", "scenario33", "scenario34")  # train2_seq.py:196
+
+
+def per_scenario_metrics(y_pred, y_true, scenario, scenarios=SCENARIOS):
+    """train2_seq.py:195-207: top-k accuracy and DBA of every scenario that has samples -> {scenario: (acc, DBA)}."""
+    y_pred, y_true, scenario = np.asarray(y_pred), np.asarray(y_true), np.asarray(scenario)
+    out = {}
+    for s in scenarios:
+        sel = scenario == s
+        if np.sum(sel) > 0:
+            out[s] = (compute_acc(y_pred[sel], y_true[sel]), compute_DBA_score(y_pred[sel], y_true[sel]))
+    return out
+
+
 @torch.no_grad()
-def validate(model, batches, ema=None):
+def validate(model, batches, ema=None, criterion=None):
     """Engine.validate (train2_seq.py:158-221): optional EMA shadow swap -> eval-mode forward (running BN stats,
-    no dropout) -> argsort -> top-k accuracy and DBA -> restore.  batches: iterable of
-    (fronts, lidars, radars, gps, beamidx).  Returns (DBA, top-1/2/3 accuracy [%], argsorted predictions)."""
+    no dropout) -> argsort -> top-k accuracy and DBA, overall and per scenario (:195-207) -> restore.  batches:
+    iterable of (fronts, lidars, radars, gps, beamidx[, scenario[, soft_target]]).  Returns (DBA, top-1/2/3 accuracy [%],
+    argsorted predictions); with scenario labels the per-scenario table is left in ``validate.last["per_scenario"]``,
+    with a criterion and soft targets the mean validation loss (:185-190, 211) in ``validate.last["loss"]``."""
     if ema is not None:
         ema.apply_shadow()
     was_training = model.training
     model.eval()
-    preds, truth = [], []
-    for fronts, lidars, radars, gps, beamidx in batches:
+    preds, truth, scen, losses = [], [], [], []
+    for batch in batches:
+        fronts, lidars, radars, gps, beamidx = batch[:5]
         logits = model(fronts, lidars, radars, gps)
         preds.append(torch.argsort(logits, dim=1, descending=True).cpu().numpy())
         truth.append(np.asarray(beamidx.cpu() if torch.is_tensor(beamidx) else beamidx))
+        if len(batch) > 5 and batch[5] is not None:
+            scen.append(np.asarray(batch[5]))
+        if criterion is not None:
+            tgt = batch[6] if len(batch) > 6 and batch[6] is not None else torch.as_tensor(truth[-1])
+            losses.append(float(criterion(logits, tgt.to(logits.device))))
     model.train(was_training)
     if ema is not None:
         ema.restore()
     p, y = np.concatenate(preds), np.concatenate(truth)
+    validate.last = dict(per_scenario=per_scenario_metrics(p, y, np.concatenate(scen)) if scen else {},
+                         loss=(sum(losses) / len(losses)) if losses else None)
     return compute_DBA_score(p, y), compute_acc(p, y), p
+
+
+validate.last = {}
+
+
+@torch.no_grad()
+def test(model, batches, target_csv="beam_pred.csv", confidence_csv="beam_pred_confidence_seq.csv"):
+    """Engine.test (train2_seq.py:224-253): eval forward -> argsorted beams -> beam_pred.csv, and the softmax
+    max-confidence of every sample (:243-246) -> beam_pred_confidence_seq.csv.  batches: iterable of
+    (fronts, lidars, radars, gps, ...).  Returns (argsorted predictions, confidences)."""
+    was_training = model.training
+    model.eval()
+    preds, conf = [], []
+    for batch in batches:
+        logits = model(*batch[:4])
+        preds.append(torch.argsort(logits, dim=1, descending=True).cpu().numpy())
+        conf.append(torch.softmax(logits, dim=1).max(dim=1)[0].cpu().numpy())
+    model.train(was_training)
+    p, c = np.concatenate(preds), np.concatenate(conf)
+    if target_csv:
+        save_pred_to_csv(p, target_csv=target_csv)
+    if confidence_csv:
+        with open(confidence_csv, "w") as f:  # pandas DataFrame(data=1-D).to_csv layout: unnamed index, column "0"
+            f.write(",0\n")
+            for i, v in enumerate(c):
+                f.write(f"{i},{float(v)!r}\n")
+    return p, c
 
 
 def save_pred_to_csv(y_pred, top_k=(1, 2, 3), target_csv="beam_pred.csv"):

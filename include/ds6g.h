@@ -231,8 +231,16 @@ int ds6g_batch_sum(const float* src, float* out, long n, int count, long stride,
 int ds6g_focal_loss(const float* logits, const float* target, float* loss, float* dlogits, int n, float alpha,
                     float gamma, float upstream, void* stream);
 /* optim.AdamW step (train2_seq.py:131,539) fused with EMA.update (train2_seq.py:315-320) */
+/* grad_scale_dev (nullable): one device float multiplied into grad_scale at run time - the clip coefficient below. */
 int ds6g_adamw_step(float* p, const float* g, float* m, float* v, float* shadow, long n, int step, float lr,
-                    float beta1, float beta2, float eps, float wd, float ema_decay, float grad_scale, void* stream);
+                    float beta1, float beta2, float eps, float wd, float ema_decay, float grad_scale,
+                    const float* grad_scale_dev, void* stream);
+/* torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) of the 30->5 training step (train2_seq_30to5.py:120) on
+ * the flat gradient arena: out[0] = pre_scale * ||g||_2, out[1] = min(1, max_norm / (out[0] + 1e-6)); the gradients are
+ * not rewritten - pass out + 1 to ds6g_adamw_step as grad_scale_dev.  One launch (last-block-done reduction in index
+ * order: deterministic).  ws: >= 8 KiB + 8 bytes, its first 4 bytes zero on first use. */
+int ds6g_grad_norm_clip(const float* g, long n, float max_norm, float pre_scale, float* out, void* ws, size_t ws_bytes,
+                        void* stream);
 /* vel_emb1..4 and the join MLP: model2_seq.py:422-425,518,536,555,574,863-869 */
 int ds6g_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K,
                           int rows_per_group, long group_stride, int relu, void* stream);

@@ -264,11 +264,15 @@ class Ctx:
     """Run options + optional capture of intermediate tensors by name."""
 
     def __init__(self, training: bool = True, dropout: bool = False, update_bn: bool = True,
-                 capture: dict | None = None):
+                 capture: dict | None = None, mask_fn=None):
         self.training = training
         self.dropout = dropout and training
         self.update_bn = update_bn
         self.capture = capture
+        # mask_fn(shape, p) -> keep mask already scaled by 1/(1-p), called once per dropout site in forward order
+        # (embd_drop of a stage, then per block attn_drop, resid_drop after proj, resid_drop after the MLP); lets a test
+        # run the oracle on the very masks the HIP path drew instead of torch's Philox stream
+        self.mask_fn = mask_fn
 
     def tap(self, name, t):
         if self.capture is not None:
@@ -320,7 +324,11 @@ def _layer(sd, p, arch, li, x, ctx):
 
 
 def _drop(x, p, ctx):
-    return F.dropout(x, p, True) if (ctx.dropout and p > 0) else x
+    if not (ctx.dropout and p > 0):
+        return x
+    if ctx.mask_fn is not None:
+        return x * ctx.mask_fn(tuple(x.shape), p)
+    return F.dropout(x, p, True)
 
 
 def _self_attention(sd, p, x, cfg, ctx):

@@ -1,0 +1,106 @@
+"""Data parallelism end to end on ONE card (replaces torch.nn.DataParallel, train2_seq.py:538):
+two fresh child processes = two ranks, each running one train_iteration of a small TransFuser with dist.attach
+(TransFuser._milestone_done -> GradReducer.ready -> bucketed all-reduce during the backward walk).  Checked:
+  * both ranks' gradient arenas equal the SUM of the two single-process shard arenas (per-shard BatchNorm);
+  * the buckets issued cover the arena exactly once, in order, ending on milestone boundaries;
+  * parameters after the AdamW step with grad_scale = 1/2 are identical on both ranks and equal the oracle AdamW on the
+    averaged gradient;
+  * ranks draw different dropout seeds; a backward without zero_grad raises instead of double-reducing."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _launch(tmp_path, seed, dropout, world=2):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), DS6G_DIST_BACKEND="gloo", DS6G_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path), str(seed),
+                                       str(dropout)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode(errors="replace"))
+    for rank, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {rank} failed:\n{outs[rank][-4000:]}"
+    return [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=True) for r in range(world)]
+
+
+def test_two_ranks_reduce_to_the_sum_of_shard_gradients(dev, tmp_path):
+    from deepsense6g_tii_amd.model import GlobalConfig, TransFuser
+    from oracle import fusion_ref as fr
+    from oracle import train_ref as tr
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dp_worker import shard
+    seed = 71
+    ranks = _launch(tmp_path, seed, 0.0)
+    # single-process shard runs (the reference semantics of one DataParallel replica each)
+    kw = dict(n_layer=1, embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
+    rcfg = fr.RefConfig(**kw)
+    sd = fr.make_state(rcfg, seed=seed)
+    single = []
+    for r in range(2):
+        model = TransFuser(GlobalConfig(**kw), dev)
+        model.load_state_dict(sd)
+        model.train()
+        loss, _ = model.train_step_loss(*shard(r, 2, rcfg, seed + 1))
+        torch.cuda.synchronize()
+        p, g = model.flat_parameters()
+        single.append(dict(grad=g.cpu().clone(), loss=float(loss)))
+        param0 = p.cpu().clone()      # train_step_loss does not touch the parameters: still the start-up weights
+        del model
+    gsum = single[0]["grad"] + single[1]["grad"]
+    scale = gsum.abs().max().item()
+    for r in range(2):
+        assert ranks[r]["world"] == 2 and ranks[r]["grad_scale"] == 0.5
+        assert abs(ranks[r]["loss"] - single[r]["loss"]) < 1e-6 * abs(single[r]["loss"]) + 1e-9
+        err = (ranks[r]["grad"] - gsum).abs().max().item()
+        assert err <= 1e-5 * scale, (r, err, scale)
+    assert torch.equal(ranks[0]["grad"], ranks[1]["grad"])          # bitwise: same sum on both ranks
+    assert torch.equal(ranks[0]["param"], ranks[1]["param"])        # replicas stay in lock-step
+    # AdamW on the averaged gradient (grad_scale = 1/world folded into the kernel)
+    ref = param0.clone()
+    m, v = torch.zeros_like(ref), torch.zeros_like(ref)
+    tr.adamw_step(ref, ranks[0]["grad"] * 0.5, m, v, 1, 1e-3)
+    assert (ranks[0]["param"] - ref).abs().max().item() < 1e-7 + 2e-6 * ref.abs().max().item()
+    # bucket list: contiguous, in order, covers [0, arena_used) exactly once, every cut on a milestone boundary
+    issued, used = ranks[0]["issued"], ranks[0]["used"]
+    assert issued == ranks[1]["issued"] and len(issued) >= 3
+    assert issued[0][0] == 0 and issued[-1][1] == used
+    for (lo, hi), (lo2, hi2) in zip(issued, issued[1:]):
+        assert hi == lo2 and hi > lo
+    ends = set(ranks[0]["milestone_end"].values())
+    assert all(hi in ends for _, hi in issued)
+    # guard against double reduction
+    for r in range(2):
+        assert open(os.path.join(tmp_path, f"guard{r}.txt")).read() == "True"
+
+
+def test_ranks_draw_independent_dropout_masks(dev, tmp_path):
+    ranks = _launch(tmp_path, 72, 0.1)
+    assert ranks[0]["seed0"] == ranks[1]["seed0"]
+    assert ranks[0]["seed"] == ranks[0]["seed0"]                    # rank 0 keeps the single-process stream
+    assert ranks[1]["seed"] != ranks[0]["seed"]
+    assert torch.isfinite(ranks[0]["grad"]).all() and torch.equal(ranks[0]["grad"], ranks[1]["grad"])

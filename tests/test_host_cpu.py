@@ -185,3 +185,56 @@ def test_grad_reducer_flushes_early_at_the_given_milestone():
     red.ready(3, 60, 90)
     red.finish()
     assert red.issued == [(0, 60), (60, 90)]
+
+
+def test_dropout_seed_differs_per_rank_and_rng_state_roundtrips():
+    """data-parallel ranks must not share dropout masks; the (seed, counter) state is checkpointed."""
+    from deepsense6g_tii_amd.model import GlobalConfig, TransFuser
+    m = TransFuser(GlobalConfig(n_layer=1), "cpu")
+    base = m._seed
+    seeds = [m.set_dropout_seed(base, r) for r in range(8)]
+    assert seeds[0] == base and len(set(seeds)) == 8 and all(0 <= s < 2 ** 64 for s in seeds)
+    m.set_dropout_seed(base, 3)
+    m._drop_counter = 12345 * 1024
+    st = m.rng_state()
+    m2 = TransFuser(GlobalConfig(n_layer=1), "cpu")
+    m2.set_rng_state(st)
+    assert (m2._seed, m2._drop_counter) == (seeds[3], 12345 * 1024)
+
+
+def test_per_scenario_metrics_and_confidence_csv(tmp_path):
+    """train2_seq.py:195-207 (per-scenario accuracy / DBA) and :243-252 (softmax max-confidence file)."""
+    rng = np.random.default_rng(0)
+    pred = np.stack([rng.permutation(64) for _ in range(12)])
+    truth = rng.integers(0, 64, 12)
+    scen = np.array(["scenario31"] * 5 + ["scenario33"] * 7)
+    table = T.per_scenario_metrics(pred, truth, scen)
+    assert set(table) == {"scenario31", "scenario33"}                 # scenarios without samples are skipped (:199)
+    acc31, dba31 = table["scenario31"]
+    assert list(acc31) == list(tr.compute_acc(pred[:5], truth[:5])) and abs(dba31 - tr.compute_dba_score(pred[:5], truth[:5])) < 1e-12
+    acc33, dba33 = table["scenario33"]
+    assert list(acc33) == list(tr.compute_acc(pred[5:], truth[5:])) and abs(dba33 - tr.compute_dba_score(pred[5:], truth[5:])) < 1e-12
+
+    class Dummy(torch.nn.Module):          # stands in for the HIP model: test() only needs a callable with train()/eval()
+        def forward(self, a, b, c, d):
+            return a
+    logits = torch.randn(5, 64, generator=torch.Generator().manual_seed(1))
+    p, c = T.test(Dummy(), [(logits[:2], None, None, None), (logits[2:], None, None, None)],
+                  target_csv=str(tmp_path / "beam_pred.csv"), confidence_csv=str(tmp_path / "conf.csv"))
+    assert np.array_equal(p, torch.argsort(logits, dim=1, descending=True).numpy())
+    assert np.allclose(c, torch.softmax(logits, 1).max(1)[0].numpy())
+    rows = (tmp_path / "conf.csv").read_text().strip().split("\n")
+    assert rows[0] == ",0" and len(rows) == 6 and abs(float(rows[3].split(",")[1]) - float(c[2])) < 1e-7
+    assert (tmp_path / "beam_pred.csv").read_text().startswith("index,top-1 beam")
+
+
+def test_bench_roofline_fraction_is_an_executed_fraction():
+    """roofline.frac must be executed matrix FLOPs / time / peak (<= 1), the algorithmic rate a separate key."""
+    import bench
+    # a Winograd record: 110 launches, algorithmic 18.12 GFLOP each, 110.2 us each (profiles/r01 numbers)
+    agg = {20000: [110, 110 * 18119393280.0, 110 * 0.1102], 12: [130, 130 * 6.6e9, 130 * 0.0663]}
+    roof = bench.roofline_from_records(agg, "f32", traffic=lambda v: None)
+    assert roof["kernel"] == "winograd_fwd_kernel<1>"
+    assert 0.4 < roof["frac"] < 0.5 and abs(roof["achieved"] - roof["frac"] * roof["peak"]) < 1e-9
+    assert roof["algorithmic_tflops"] > roof["achieved"] * 2.2
+    assert roof["frac"] <= 1.0 and roof["largest_direct_kernel"]["frac"] <= 1.0

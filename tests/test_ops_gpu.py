@@ -476,7 +476,7 @@ def test_focal_adamw_small_linear(dev):
         sh_ref = 0.001 * ref.detach() + 0.999 * sh_ref
         gradg = grad.cuda()
         lib().adamw_step(pg.data_ptr(), gradg.data_ptr(), m.data_ptr(), v.data_ptr(), shadow.data_ptr(), n, step,
-                         1e-3, 0.9, 0.999, 1e-8, 0.01, 0.999, 1.0, st)
+                         1e-3, 0.9, 0.999, 1e-8, 0.01, 0.999, 1.0, 0, st)
     close(pg, ref.detach(), 1e-6, 1e-6)
     close(shadow, sh_ref, 1e-6, 1e-6)
 

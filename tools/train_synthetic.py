@@ -15,6 +15,7 @@ ap.add_argument("--batch", type=int, default=12)
 ap.add_argument("--lr", type=float, default=1e-4)
 ap.add_argument("--pool", type=int, default=16, help="distinct training batches (seeds)")
 ap.add_argument("--eval-batches", type=int, default=8)
+ap.add_argument("--eval-every", type=int, default=50)
 ap.add_argument("--ema", type=int, default=0)
 ap.add_argument("--dtype", default="f32", help="matrix-core mode (ops.set_compute_mode)")
 args = ap.parse_args()
@@ -45,7 +46,7 @@ t0 = time.time()
 for step in range(1, args.steps + 1):
     f, l, r, g, t, _ = pool[step % args.pool]
     loss, _ = train_iteration(model, opt, (f, l, r, g, t), ema)
-    if step % 50 == 0 or step == args.steps:
+    if step % args.eval_every == 0 or step == args.steps:
         torch.cuda.synchronize()
         dba, acc = evaluate()
         model.train()
