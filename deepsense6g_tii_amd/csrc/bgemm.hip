@@ -1,0 +1,610 @@
+// Implicit-GEMM convolution / linear kernels on bf16-STORED operands (the real bf16 path of BASELINE configs[1] / [4]:
+// activations and a bf16 shadow of the weights live in HBM as bf16, accumulation is fp32, master weights / statistics /
+// loss / optimizer stay fp32).  Same three products as igemm.hip,
+//   FWD   : y[m][o]      = sum_{r,s,c} x[n, oh*st-p+r, ow*st-p+s, c] * w[o][r][s][c]
+//   DGRAD : dx[m][c]     = sum_{r,s,o} dy[n, h+p-r, w+p-s, o] * w[o][r][s][c]               (stride 1)
+//   WGRAD : dw[o][r,s,c] = sum_{pixels} dy[pixel][o] * x[n, oh*st-p+r, ow*st-p+s, c]         (split-K, fp32 slabs)
+// on NHWC bf16 activations and OHWI bf16 weights; a Linear layer is the 1x1 case over ONE 1 x M "image".
+// Reference call sites: model2_seq.py:510-512,528-530,546-548,565-567 (BasicBlock convs), :83-90,:97-99,:109,:121-126
+// (GPT linears); the reference itself has no reduced-precision mode (train2_seq.py:111-116 casts to fp32).
+//
+// What differs from igemm.hip (fp32 tiles, operands rounded on the way into the MFMA):
+//   * tiles travel HBM -> LDS as bf16 by LDS-DMA (half the bytes), k-tile = 64 elements, and the fragments are fed to
+//     v_mfma_f32_32x32x16_bf16 exactly as they lie in LDS - no conversion, no VALU in the MFMA loop;
+//   * K-contiguous sources (im2col rows of x / dy, weight rows of the forward) use a [row][64] image of 128-byte rows whose
+//     16-B chunk index is XOR-swizzled by (row >> 1) & 7 on the SOURCE address: one conflict-free ds_read_b128 per 32-row
+//     fragment and 16-deep k-step;
+//   * row-contiguous sources (both wgrad operands, the dgrad weights) are staged as they lie in memory, [k][cols], and
+//     read TRANSPOSED by ds_read_b64_tr_b16 (gfx950's LDS transpose read: two per fragment and k-step); the 64-B column
+//     segment index is XOR-swizzled by the k row so that the four rows of one transposed read hit different banks;
+//   * a bf16 output tile is rounded once from the fp32 accumulators and leaves through LDS, so that rows are stored as
+//     16-byte pieces instead of 2-byte elements.
+// Only the wave-uniform k walk of igemm.hip exists here (channel counts multiples of 64; wgrad: see bgemm_wgrad_walk):
+// every layer of the model but the 4-channel stems qualifies, and the stems keep the fp32-storage kernel.
+#include "common.h"
+
+void* ds6g_prof_open(int variant, double flops, hipStream_t st);
+void ds6g_prof_close(void* rec, hipStream_t st);
+// igemm.hip: sums split-K slabs (weight gradient + optional bias-gradient tail) into the fp32 gradient
+int ds6g_internal_splitk_reduce(const float* ws, float* dw, long n4, float* dbias, long m4, int splits, size_t stride,
+                                int accumulate, int accumulate_b, hipStream_t st);
+
+namespace {
+
+enum { B_FWD = 0, B_DGRAD = 1, B_WGRAD = 2 };
+constexpr int BK = 64;  // k-tile depth in elements (128 B of a K-contiguous row; 64 rows of a k-major image)
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct BgemmParams {
+    const __bf16* a_src;
+    const __bf16* b_src;
+    void* out;            // float* (fp32 output / split-K slabs) or __bf16*
+    int N, H, W, C;       // input-side tensor (x / dx), NHWC
+    int Ho, Wo, K;        // output-side tensor (y / dy)
+    int R, S, stride, pad;
+    int Mg, Ng, Kg;
+    const float* bias;
+    const float* residual;   // fp32 [Mg][Ng] (the GPT residual stream stays fp32)
+    const void* mask_src;    // ReLU mask source [Mg][Ng], fp32 or bf16 (mask16)
+    int mask16;
+    int relu;
+    int accumulate;
+    uint32_t drop_thr;
+    float drop_scale;
+    uint64_t seed, seed_off;
+    int k_per_split;      // multiple of 64
+    size_t split_stride;
+    int tiles_n;
+    int wg_rows;          // WGRAD: 0 = a k-tile of 64 pixels stays inside one output row; else output rows per k-tile
+    int want_colsum;
+    unsigned a_bytes, b_bytes;
+};
+
+__device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(unsigned long)(lds_void*)p; }
+
+// MODE / BM x BN tile / OUT16: bf16 output through LDS (else fp32, direct) / EPI: fused epilogue (bias, ReLU, mask,
+// dropout, residual, accumulate) instead of a plain store
+template <int MODE, int BM, int BN, int OUT16, int EPI>
+__global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams p) {
+    constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 MFMA tiles per wave (wave grid 2 x 2)
+    constexpr bool A_T = (MODE == B_WGRAD);            // operand staged [k][cols], read transposed
+    constexpr bool B_T = (MODE != B_FWD);
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int A_LD = A_BYTES / 4096, B_LD = B_BYTES / 4096;  // 1-KiB DMA pieces per wave and k-tile
+    constexpr int A_RB = BM * 2, B_RB = BN * 2;                  // row bytes of a k-major image
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    // ONE shared object (a second one beside LDS-DMA staging makes hipcc drain vmcnt before every fragment read)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, khalf = lane >> 5;
+    int wg;
+    {   // XCD-aware tile order (bijective for any grid), as igemm.hip
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.z;
+    const int kbegin = (MODE == B_WGRAD) ? split * p.k_per_split : 0;
+    const int kend = (MODE == B_WGRAD) ? min(p.Kg, kbegin + p.k_per_split) : p.Kg;
+    const int nk = (kend - kbegin + BK - 1) / BK;
+
+    const i32x4 a_rsrc = make_srd(p.a_src, p.a_bytes);
+    i32x4 b_rsrc = make_srd(p.b_src, p.b_bytes);
+
+    // ---- lane -> (row, element offset) of its 16-B slot in DMA piece `pi` of an image ----------------------------
+    // K image [rows][64]: piece = 8 rows x 128 B; slot (row, phys chunk) holds logical chunk (phys ^ (row >> 1) & 7)
+    auto kimg_row = [&](int pi) { return pi * 8 + (lane >> 3); };
+    auto kimg_kel = [&](int pi) { return (((lane & 7) ^ ((kimg_row(pi) >> 1) & 7)) << 3); };
+    // T image [64 k rows][cols], RB bytes per row: piece = 1024 / RB rows; 64-B segment index swizzled by the row
+    auto timg_row = [&](int pi, int RB) { return pi * (1024 / RB) + lane / (RB / 16); };
+    auto timg_cel = [&](int pi, int RB) {
+        const int row = timg_row(pi, RB), slot = lane % (RB / 16);
+        const int seg = slot >> 2, within = slot & 3;
+        const int lseg = (RB == 256) ? (seg ^ (row & 3)) : (RB == 128 ? (seg ^ ((row >> 1) & 1)) : seg);
+        return (lseg * 4 + within) * 8;
+    };
+
+    // ---- wave-uniform walk state (SGPRs) + per-lane constant byte offsets, as igemm.hip's FAST walk ---------------
+    int u_c0 = 0, u_r = 0, u_s = 0;
+    unsigned u_kb = 0;
+    int u_kpos = kbegin, u_n = 0, u_oh = 0, u_ow = 0;
+    unsigned a_vo[A_LD], b_vo[B_LD];
+    [[maybe_unused]] int a_y[A_LD], a_x[A_LD], a_c[A_LD];
+    [[maybe_unused]] unsigned a_base[A_LD];
+    [[maybe_unused]] bool a_ok[A_LD], b_ok[B_LD];
+    [[maybe_unused]] int a_kr[A_LD], b_kr[B_LD], b_ihl[B_LD], b_iwl[B_LD];
+
+    auto retap = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            if (MODE == B_FWD) {
+                const int ih = a_y[i] + u_r, iw = a_x[i] + u_s;
+                const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                a_vo[i] = ok ? (a_base[i] + (unsigned)((ih * p.W + iw) * p.C + a_c[i])) * 2u : OOB_OFF;
+            } else if (MODE == B_DGRAD) {
+                const int oh = a_y[i] - u_r, ow = a_x[i] - u_s;
+                const bool ok = a_ok[i] && (unsigned)oh < (unsigned)p.Ho && (unsigned)ow < (unsigned)p.Wo;
+                a_vo[i] = ok ? (a_base[i] + (unsigned)((oh * p.Wo + ow) * p.K + a_c[i])) * 2u : OOB_OFF;
+            }
+        }
+    };
+
+    if (MODE == B_FWD || MODE == B_DGRAD) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int pi = i * 4 + wave;
+            const int m = m0 + kimg_row(pi);
+            a_ok[i] = m < p.Mg;
+            const int mm = a_ok[i] ? m : 0;
+            a_c[i] = kimg_kel(pi);
+            if (MODE == B_FWD) {
+                const int ow = mm % p.Wo, t = mm / p.Wo, oh = t % p.Ho, n = t / p.Ho;
+                a_y[i] = oh * p.stride - p.pad;
+                a_x[i] = ow * p.stride - p.pad;
+                a_base[i] = (unsigned)n * (unsigned)(p.H * p.W * p.C);
+            } else {
+                const int w = mm % p.W, t = mm / p.W, h = t % p.H, n = t / p.H;
+                a_y[i] = h + p.pad;
+                a_x[i] = w + p.pad;
+                a_base[i] = (unsigned)n * (unsigned)(p.Ho * p.Wo * p.K);
+            }
+        }
+        retap();
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int pi = i * 4 + wave;
+            if (MODE == B_FWD) {
+                const int n = n0 + kimg_row(pi);
+                b_vo[i] = n < p.Ng ? ((unsigned)n * (unsigned)p.Kg + (unsigned)kimg_kel(pi)) * 2u : OOB_OFF;
+            } else {  // weights as [k = out channel][col = in channel] of the current tap
+                const int col = n0 + timg_cel(pi, B_RB);
+                b_vo[i] = col < p.Ng ? ((unsigned)(timg_row(pi, B_RB) * (p.R * p.S) * p.C) + (unsigned)col) * 2u : OOB_OFF;
+            }
+        }
+    } else {
+        {   // pixel kbegin -> (image, output row, output column)
+            const int t = kbegin / p.Wo;
+            u_ow = p.wg_rows == 0 ? kbegin % p.Wo : 0;
+            u_oh = t % p.Ho;
+            u_n = t / p.Ho;
+        }
+        const int shift = (p.pad * p.W + p.pad) * p.C;  // negative tap offsets folded into the descriptor base
+        b_rsrc = make_srd(p.b_src - shift, p.b_bytes + (unsigned)shift * 2u);
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int pi = i * 4 + wave;
+            a_kr[i] = timg_row(pi, A_RB);
+            const int col = m0 + timg_cel(pi, A_RB);
+            a_ok[i] = col < p.Mg;
+            a_vo[i] = ((unsigned)(a_kr[i] * p.K) + (unsigned)col) * 2u;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int pi = i * 4 + wave;
+            b_kr[i] = timg_row(pi, B_RB);
+            const int col = n0 + timg_cel(pi, B_RB);
+            b_ok[i] = col < p.Ng;
+            const int cc = b_ok[i] ? col : 0;
+            const int tap = cc / p.C, c = cc - tap * p.C;
+            const int br = tap / p.S, bs = tap - br * p.S;
+            const int dl_oh = p.wg_rows == 0 ? 0 : b_kr[i] / p.Wo;
+            const int dl_ow = p.wg_rows == 0 ? b_kr[i] : b_kr[i] % p.Wo;
+            b_ihl[i] = dl_oh * p.stride - p.pad + br;
+            b_iwl[i] = dl_ow * p.stride - p.pad + bs;
+            b_vo[i] = (unsigned)(c + (b_ihl[i] * p.W + b_iwl[i]) * p.C + shift) * 2u;
+        }
+    }
+
+    // DMA of the next k-tile into stage `st`; the walk state advances by one k-tile
+    auto issue_tiles = [&](int st) {
+        const unsigned la = lds_off(lds + st * STAGE), lb = la + A_BYTES;
+        if (MODE == B_FWD || MODE == B_DGRAD) {
+            const unsigned sa = (unsigned)u_c0 * 2u;
+            const unsigned sb = (MODE == B_FWD) ? u_kb : (unsigned)((u_c0 * (p.R * p.S) + u_r * p.S + u_s) * p.C) * 2u;
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) dma16(a_rsrc, la + (unsigned)(i * 4 + wave) * 1024u, a_vo[i], sa);
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) dma16(b_rsrc, lb + (unsigned)(i * 4 + wave) * 1024u, b_vo[i], sb);
+            u_kb += BK * 2;
+            u_c0 += BK;
+            if (u_c0 == ((MODE == B_FWD) ? p.C : p.K)) {
+                u_c0 = 0;
+                if (++u_s == p.S) { u_s = 0; ++u_r; }
+                retap();
+            }
+        } else {
+            const int rows_left = kend - u_kpos;
+            const unsigned sa = (unsigned)(u_kpos * p.K) * 2u;
+            const int ihu = u_oh * p.stride, iwu = u_ow * p.stride;
+            const unsigned sb = (unsigned)(((u_n * p.H + ihu) * p.W + iwu) * p.C) * 2u;
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                const bool ok = a_ok[i] && a_kr[i] < rows_left;
+                dma16(a_rsrc, la + (unsigned)(i * 4 + wave) * 1024u, ok ? a_vo[i] : OOB_OFF, sa);
+            }
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) {
+                const bool ok = b_ok[i] && b_kr[i] < rows_left && (unsigned)(ihu + b_ihl[i]) < (unsigned)p.H &&
+                                (unsigned)(iwu + b_iwl[i]) < (unsigned)p.W;
+                dma16(b_rsrc, lb + (unsigned)(i * 4 + wave) * 1024u, ok ? b_vo[i] : OOB_OFF, sb);
+            }
+            u_kpos += BK;
+            if (p.wg_rows == 0) {
+                u_ow += BK;
+                if (u_ow >= p.Wo) {
+                    u_ow = 0;
+                    if (++u_oh == p.Ho) { u_oh = 0; ++u_n; }
+                }
+            } else {
+                u_oh += p.wg_rows;
+                if (u_oh >= p.Ho) { u_oh = 0; ++u_n; }
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- fragment addresses (bytes inside an operand image) --------------------------------------------------------
+    // K image: lane (row, half) reads logical chunk 2s + half of its row for k-step s: one ds_read_b128
+    const unsigned ka_row = (unsigned)((wm * (BM / 2) + l31) * 128), kb_row = (unsigned)((wn * (BN / 2) + l31) * 128);
+    const unsigned kswz = (unsigned)((l31 >> 1) & 7);
+    // T image: lane 4q + pp of a 16-lane group addresses row 16s + 8 half + 4t + q, columns c0 + 16 (group & 1) + 4 pp .. + 3
+    const int tq = (lane >> 2) & 3, tpp = lane & 3, tgrp = (lane >> 4) & 1;
+    auto t_addr = [&](int RB, int cbase, int s, int t) {
+        const int row = 16 * s + 8 * khalf + 4 * t + tq;
+        const int col = cbase + 16 * tgrp + 4 * tpp;
+        const int seg = col >> 5;
+        const int pseg = (RB == 256) ? (seg ^ (row & 3)) : (RB == 128 ? (seg ^ ((row >> 1) & 1)) : seg);
+        return (unsigned)(row * RB + pseg * 64 + (col & 31) * 2);
+    };
+
+    float csum = 0.f;  // WGRAD bias gradient: column sums of the dy tile (threads tid < BM of the tile_n == 0 blocks)
+    const bool do_csum = (MODE == B_WGRAD) && p.want_colsum && tile_n == 0 && tid < BM;
+
+    auto compute = [&](int st) {
+        const unsigned char* Ac = lds + st * STAGE;
+        const unsigned char* Bc = Ac + A_BYTES;
+        if (MODE == B_WGRAD && do_csum) {
+            const int seg = tid >> 5;
+#pragma unroll 8
+            for (int k = 0; k < BK; ++k) {
+                const int pseg = (A_RB == 256) ? (seg ^ (k & 3)) : (seg ^ ((k >> 1) & 1));
+                csum += (float)*reinterpret_cast<const __bf16*>(Ac + k * A_RB + pseg * 64 + (tid & 31) * 2);
+            }
+        }
+        bf16x8 af[4][TM], bfr[4][TN];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (A_T) {
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(lds_void*)(Ac + t_addr(A_RB, wm * (BM / 2) + i * 32, s, 0)));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(lds_void*)(Ac + t_addr(A_RB, wm * (BM / 2) + i * 32, s, 1)));
+                    af[s][i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                } else {
+                    af[s][i] = *reinterpret_cast<const bf16x8*>(Ac + ka_row + i * 32 * 128 + ((((unsigned)(2 * s + khalf)) ^ kswz) << 4));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (B_T) {
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(lds_void*)(Bc + t_addr(B_RB, wn * (BN / 2) + j * 32, s, 0)));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(lds_void*)(Bc + t_addr(B_RB, wn * (BN / 2) + j * 32, s, 1)));
+                    bfr[s][j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                } else {
+                    bfr[s][j] = *reinterpret_cast<const bf16x8*>(Bc + kb_row + j * 32 * 128 + ((((unsigned)(2 * s + khalf)) ^ kswz) << 4));
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i], bfr[s][j], acc[i][j], 0, 0, 0);
+    };
+
+    // two stages: the DMA of tile t+1 flies under the MFMAs of tile t; one wait + barrier per k-tile
+    if (nk > 0) issue_tiles(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) issue_tiles((kt + 1) & 1);
+        compute(kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[row][col], col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -------------------------
+    if (!OUT16) {
+        float* outp = reinterpret_cast<float*>(p.out) + ((MODE == B_WGRAD) ? (size_t)split * p.split_stride : (size_t)0);
+        if (MODE == B_WGRAD && do_csum && m0 + tid < p.Mg) outp[(size_t)p.Mg * p.Ng + m0 + tid] = csum;
+        const unsigned nbytes = (unsigned)p.Mg * (unsigned)p.Ng * 4u;
+        const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, nbytes, 0x00020000);
+        const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual ? p.residual : outp), 0, nbytes, 0x00020000);
+        const unsigned rowbytes = (unsigned)p.Ng * 4u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+                const int row0 = m0 + wm * (BM / 2) + i * 32 + 4 * khalf;
+                const bool cok = col < p.Ng;
+                const float bias = (EPI && p.bias && cok) ? p.bias[col] : 0.f;
+                const unsigned base = cok ? (unsigned)row0 * rowbytes + (unsigned)col * 4u : OOB_OFF;
+                const unsigned e0 = (unsigned)row0 * (unsigned)p.Ng + (unsigned)col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned dr = (unsigned)((r & 3) + 8 * (r >> 2));
+                    const unsigned off = base + dr * rowbytes;
+                    float v = acc[i][j][r];
+                    if (EPI) {
+                        v += bias;
+                        if (p.relu == 1) v = fmaxf(v, 0.f);
+                        if (p.drop_thr)
+                            v = ds6g_keep(p.seed, p.seed_off + (uint64_t)(e0 + dr * (unsigned)p.Ng), p.drop_thr) ? v * p.drop_scale : 0.f;
+                        if (p.residual) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, off, 0, 0));
+                    }
+                    if (MODE != B_WGRAD && p.accumulate) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(o_rsrc, off, 0, 0));
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, off, 0, 0);
+                }
+            }
+        }
+        return;
+    }
+    // bf16 output: epilogue arithmetic in fp32 on the accumulators, one rounding, then through a wave-private LDS patch
+    // [BM/2 rows][BN/2 cols] so that global stores are 16-byte row pieces (the loop's last barrier has been passed by
+    // every wave: the staging buffers are free)
+    {
+        __bf16* outp = reinterpret_cast<__bf16*>(p.out);
+        constexpr int PR = BM / 2, PC = BN / 2;
+        __bf16* patch = reinterpret_cast<__bf16*>(lds) + wave * PR * PC;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * PC + j * 32 + l31;
+                const int row0 = m0 + wm * PR + i * 32 + 4 * khalf;
+                const bool cok = col < p.Ng;
+                const float bias = (EPI && p.bias && cok) ? p.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    float v = acc[i][j][r];
+                    if (EPI) {
+                        v += bias;
+                        if (p.relu == 1) v = fmaxf(v, 0.f);
+                        const size_t e = (size_t)(row0 + dr) * p.Ng + col;
+                        if (p.mask_src && cok && row0 + dr < p.Mg) {
+                            const float mv = p.mask16 ? (float)reinterpret_cast<const __bf16*>(p.mask_src)[e]
+                                                      : reinterpret_cast<const float*>(p.mask_src)[e];
+                            v = mv > 0.f ? v : 0.f;
+                        }
+                        if (p.drop_thr) v = ds6g_keep(p.seed, p.seed_off + (uint64_t)e, p.drop_thr) ? v * p.drop_scale : 0.f;
+                    }
+                    patch[(i * 32 + 4 * khalf + dr) * PC + j * 32 + l31] = (__bf16)v;
+                }
+            }
+        }
+        // wave-private patch: the wave's own LDS writes are ordered before its reads by the compiler's lgkmcnt waits
+        constexpr int PPR = PC / 8;  // 16-B pieces per patch row
+#pragma unroll
+        for (int t = 0; t < PR * PPR / 64; ++t) {
+            const int idx = t * 64 + lane;
+            const int rl = idx / PPR, pc = idx - rl * PPR;
+            const int grow = m0 + wm * PR + rl, gcol = n0 + wn * PC + pc * 8;
+            if (grow < p.Mg && gcol < p.Ng) {
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + rl * PC + pc * 8);
+                bf16x8* dst = reinterpret_cast<bf16x8*>(outp + (size_t)grow * p.Ng + gcol);
+                if (p.accumulate) {
+                    const bf16x8 old = *dst;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] + (float)old[e]);
+                }
+                *dst = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+int g_bg_min_blocks = 512;  // 128 x 128 tiles once they still give this many workgroups, else 64 x 64
+
+void fill_conv(BgemmParams& p, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
+    p = BgemmParams{};
+    p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+    p.Ho = (H + 2 * pad - R) / stride + 1;
+    p.Wo = (W + 2 * pad - S) / stride + 1;
+    p.drop_scale = 1.f;
+}
+
+// wgrad: the 64 pixels of a k-tile share one (image, output row), or cover whole output rows of one image
+bool bgemm_wgrad_walk(BgemmParams& p) {
+    if (p.Wo % BK == 0 || p.N * p.Ho == 1) { p.wg_rows = 0; return true; }
+    if (BK % p.Wo == 0 && p.Ho % (BK / p.Wo) == 0) { p.wg_rows = BK / p.Wo; return true; }
+    return false;
+}
+
+template <int MODE, int OUT16, int EPI>
+int launch_tiles(BgemmParams& p, int splits, int tile, hipStream_t st) {
+    dim3 block(256);
+    if (tile == 0) {
+        p.tiles_n = cdiv(p.Ng, 128);
+        dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, 1, splits);
+        hipLaunchKernelGGL((bgemm_kernel<MODE, 128, 128, OUT16, EPI>), grid, block, 0, st, p);
+    } else {
+        p.tiles_n = cdiv(p.Ng, 64);
+        dim3 grid(cdiv(p.Mg, 64) * p.tiles_n, 1, splits);
+        hipLaunchKernelGGL((bgemm_kernel<MODE, 64, 64, OUT16, EPI>), grid, block, 0, st, p);
+    }
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+template <int MODE>
+int launch_bgemm(BgemmParams& p, int out16, int splits, int tile, hipStream_t st) {
+    if ((size_t)p.Mg * p.Ng * 4 >= OOB_OFF) return DS6G_ERR_ARG;
+    const bool epi = p.bias || p.relu || p.mask_src || p.drop_thr || p.residual;
+    void* rec = ds6g_prof_open(30000 + 100 * out16 + 10 * MODE + tile, 2.0 * p.Mg * p.Ng * p.Kg, st);
+    int rc;
+    if (MODE == B_WGRAD) rc = launch_tiles<MODE, 0, 0>(p, splits, tile, st);
+    else if (out16) rc = epi ? launch_tiles<MODE, 1, 1>(p, splits, tile, st) : launch_tiles<MODE, 1, 0>(p, splits, tile, st);
+    else rc = epi ? launch_tiles<MODE, 0, 1>(p, splits, tile, st) : launch_tiles<MODE, 0, 0>(p, splits, tile, st);
+    ds6g_prof_close(rec, st);
+    return rc;
+}
+
+int pick_tile(int Mg, int Ng, long splits) {
+    return ((long)cdiv(Mg, 128) * cdiv(Ng, 128) * splits >= g_bg_min_blocks && Mg > 64 && Ng > 64) ? 0 : 1;
+}
+
+int run_wgrad(BgemmParams& p, float* dw, int accumulate, float* dbias, float* ws, size_t ws_bytes, hipStream_t st) {
+    const long out_elems = (long)p.Mg * p.Ng;
+    DS6G_CHECK_ARG(out_elems % 4 == 0 && p.Mg % 4 == 0);
+    const long slab_elems = out_elems + (dbias ? p.Mg : 0);
+    const int tile = (p.Mg >= 128 && p.Ng >= 128) ? 0 : 1;
+    const long tiles = (long)cdiv(p.Mg, tile == 0 ? 128 : 64) * cdiv(p.Ng, tile == 0 ? 128 : 64);
+    long splits = (1024 + tiles - 1) / tiles;
+    const long max_by_k = (p.Kg + 4 * BK - 1) / (4 * BK);   // >= 4 k-tiles per split
+    if (splits > max_by_k) splits = max_by_k;
+    const long max_by_ws = (long)(ws_bytes / (slab_elems * sizeof(float)));
+    if (splits > max_by_ws) splits = max_by_ws;
+    if (splits < 1) splits = 1;
+    const int kps = cdiv(cdiv(p.Kg, splits), BK) * BK;
+    splits = cdiv(p.Kg, kps);
+    p.k_per_split = kps;
+    p.split_stride = (size_t)slab_elems;
+    p.want_colsum = dbias != nullptr;
+    if (splits == 1 && !accumulate && !dbias) {
+        p.out = dw;
+        return launch_bgemm<B_WGRAD>(p, 0, 1, tile, st);
+    }
+    DS6G_CHECK_ARG(ws != nullptr && (size_t)splits * slab_elems * sizeof(float) <= ws_bytes);
+    p.out = ws;
+    const int rc = launch_bgemm<B_WGRAD>(p, 0, (int)splits, tile, st);
+    if (rc) return rc;
+    return ds6g_internal_splitk_reduce(ws, dw, out_elems / 4, dbias, dbias ? p.Mg / 4 : 0, (int)splits, (size_t)slab_elems,
+                                       accumulate, accumulate, st);
+}
+
+bool sizes_ok(const BgemmParams& p) {
+    const size_t x = (size_t)p.N * p.H * p.W * p.C * 2, y = (size_t)p.N * p.Ho * p.Wo * p.K * 2, w = (size_t)p.K * p.R * p.S * p.C * 2;
+    return x < OOB_OFF && y < OOB_OFF && w < OOB_OFF;
+}
+
+}  // namespace
+
+extern "C" {
+
+// y = conv(x, w): x [N][H][W][C] bf16, w [K][R][S][C] bf16 (the bf16 weight shadow), y [N][Ho][Wo][K] bf16 (out16) or fp32.
+// C % 64 == 0, K % 8 == 0.
+int ds6g_bf16_conv2d_fwd(const void* x, const void* w, void* y, int out16, int N, int H, int W, int C, int K, int R, int S,
+                         int stride, int pad, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && w && y && C % BK == 0 && K % 8 == 0 && N > 0);
+    BgemmParams p;
+    fill_conv(p, N, H, W, C, K, R, S, stride, pad);
+    DS6G_CHECK_ARG(sizes_ok(p));
+    p.a_src = (const __bf16*)x; p.b_src = (const __bf16*)w; p.out = y;
+    p.a_bytes = (unsigned)((size_t)N * H * W * C * 2); p.b_bytes = (unsigned)((size_t)K * R * S * C * 2);
+    p.Mg = N * p.Ho * p.Wo; p.Ng = K; p.Kg = R * S * C;
+    return launch_bgemm<B_FWD>(p, out16, 1, pick_tile(p.Mg, p.Ng, 1), (hipStream_t)stream);
+}
+
+// dx (+)= conv^T(dy, w), stride 1 only (the strided layers keep the fp32-storage kernel): dy bf16, w bf16, dx bf16 / fp32.
+// K % 64 == 0, C % 8 == 0.
+int ds6g_bf16_conv2d_dgrad(const void* dy, const void* w, void* dx, int out16, int N, int H, int W, int C, int K, int R,
+                           int S, int stride, int pad, int accumulate, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(dy && w && dx && K % BK == 0 && C % 8 == 0 && stride == 1);
+    BgemmParams p;
+    fill_conv(p, N, H, W, C, K, R, S, stride, pad);
+    DS6G_CHECK_ARG(sizes_ok(p));
+    p.a_src = (const __bf16*)dy; p.b_src = (const __bf16*)w; p.out = dx; p.accumulate = accumulate;
+    p.a_bytes = (unsigned)((size_t)N * p.Ho * p.Wo * K * 2); p.b_bytes = (unsigned)((size_t)K * R * S * C * 2);
+    p.Mg = N * H * W; p.Ng = C; p.Kg = R * S * K;
+    return launch_bgemm<B_DGRAD>(p, out16, 1, pick_tile(p.Mg, p.Ng, 1), (hipStream_t)stream);
+}
+
+// dw (+)= dy^T im2col(x): x, dy bf16 -> dw fp32 [K][R][S][C] (the gradient arena).  ws: split-K slabs.
+int ds6g_bf16_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
+                           int stride, int pad, int accumulate, float* ws, size_t ws_bytes, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && dy && dw && C % 8 == 0 && K % 8 == 0);
+    BgemmParams p;
+    fill_conv(p, N, H, W, C, K, R, S, stride, pad);
+    DS6G_CHECK_ARG(sizes_ok(p) && bgemm_wgrad_walk(p));
+    p.a_src = (const __bf16*)dy; p.b_src = (const __bf16*)x;
+    p.a_bytes = (unsigned)((size_t)N * p.Ho * p.Wo * K * 2); p.b_bytes = (unsigned)((size_t)N * H * W * C * 2);
+    p.Mg = K; p.Ng = R * S * C; p.Kg = N * p.Ho * p.Wo;
+    return run_wgrad(p, dw, accumulate, nullptr, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// y[M][N] = residual + dropout(act(x[M][K] @ w[N][K]^T + bias)): x, w bf16; bias, residual fp32; y bf16 (out16) or fp32.
+// K % 64 == 0, N % 8 == 0.
+int ds6g_bf16_linear_fwd(const void* x, const void* w, const float* bias, void* y, int out16, int M, int N, int K, int relu,
+                         const float* residual, float drop_p, uint64_t seed, uint64_t seed_off, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && w && y && K % BK == 0 && N % 8 == 0 && M > 0 && drop_p >= 0.f && drop_p < 1.f);
+    DS6G_CHECK_ARG(!(out16 && residual));   // the residual stream is fp32: a fused residual add writes fp32
+    BgemmParams p;
+    fill_conv(p, 1, 1, M, K, N, 1, 1, 1, 0);
+    DS6G_CHECK_ARG(sizes_ok(p));
+    p.a_src = (const __bf16*)x; p.b_src = (const __bf16*)w; p.out = y; p.bias = bias; p.relu = relu; p.residual = residual;
+    p.drop_thr = ds6g_drop_threshold(drop_p);
+    p.drop_scale = 1.f / (1.f - drop_p);
+    p.seed = seed; p.seed_off = seed_off;
+    p.a_bytes = (unsigned)((size_t)M * K * 2); p.b_bytes = (unsigned)((size_t)N * K * 2);
+    p.Mg = M; p.Ng = N; p.Kg = K;
+    return launch_bgemm<B_FWD>(p, out16, 1, pick_tile(M, N, 1), (hipStream_t)stream);
+}
+
+// dx[M][K] (+)= (dy[M][N] @ w[N][K]) * (mask_src > 0): dy, w bf16; mask_src [M][K] bf16 (mask16) or fp32, bf16 output only;
+// dx bf16 (out16) or fp32.  N % 64 == 0, K % 8 == 0.
+int ds6g_bf16_linear_dgrad(const void* dy, const void* w, void* dx, int out16, int M, int N, int K, const void* mask_src,
+                           int mask16, int accumulate, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(dy && w && dx && N % BK == 0 && K % 8 == 0);
+    DS6G_CHECK_ARG(!(mask_src && !out16));
+    BgemmParams p;
+    fill_conv(p, 1, 1, M, K, N, 1, 1, 1, 0);
+    DS6G_CHECK_ARG(sizes_ok(p));
+    p.a_src = (const __bf16*)dy; p.b_src = (const __bf16*)w; p.out = dx; p.mask_src = mask_src; p.mask16 = mask16;
+    p.accumulate = accumulate;
+    p.a_bytes = (unsigned)((size_t)M * N * 2); p.b_bytes = (unsigned)((size_t)N * K * 2);
+    p.Mg = M; p.Ng = K; p.Kg = N;
+    return launch_bgemm<B_DGRAD>(p, out16, 1, pick_tile(M, K, 1), (hipStream_t)stream);
+}
+
+// dw[N][K] (+)= dy[M][N]^T @ x[M][K] (fp32, the gradient arena); dbias[N] (+)= column sums of dy (nullable): x, dy bf16.
+int ds6g_bf16_linear_wgrad(const void* x, const void* dy, float* dw, float* dbias, int M, int N, int K, int accumulate,
+                           float* ws, size_t ws_bytes, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && dy && dw && K % 8 == 0 && N % 8 == 0);
+    BgemmParams p;
+    fill_conv(p, 1, 1, M, K, N, 1, 1, 1, 0);
+    DS6G_CHECK_ARG(sizes_ok(p) && bgemm_wgrad_walk(p));
+    p.a_src = (const __bf16*)dy; p.b_src = (const __bf16*)x;
+    p.a_bytes = (unsigned)((size_t)M * N * 2); p.b_bytes = (unsigned)((size_t)M * K * 2);
+    p.Mg = N; p.Ng = K; p.Kg = M;
+    return run_wgrad(p, dw, accumulate, dbias, ws, ws_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -923,6 +923,15 @@ int ds6g_profile_end(int* variants, double* flops, float* ms, int cap) {
 
 }  // extern "C"
 
+// shared with bgemm.hip: the split-K slab reduction (weight gradient + optional bias-gradient tail)
+int ds6g_internal_splitk_reduce(const float* ws, float* dw, long n4, float* dbias, long m4, int splits, size_t stride,
+                                int accumulate, int accumulate_b, hipStream_t st) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n4 + m4, RED_COLS)), dim3(256), 0, st, ws, dw, n4, dbias, m4, splits,
+                       stride, accumulate, accumulate_b);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
 // shared with winograd.hip: open / close one profiler record around a kernel launch (no-ops unless profiling is on)
 void* ds6g_prof_open(int variant, double flops, hipStream_t st) {
     if (!g_prof || g_prof->size() >= g_prof_cap) return nullptr;

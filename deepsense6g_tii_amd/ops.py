@@ -348,3 +348,80 @@ def set_compute_mode(mode: str):
 
 def get_compute_mode() -> str:
     return {v: k for k, v in _MODES.items()}[lib().get_compute_mode()]
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16-stored operands (csrc/bgemm.hip): activations / weight shadow bf16, accumulation fp32
+BF16 = torch.bfloat16
+
+
+def _chk16(t, *shape):
+    assert t.dtype == BF16 and t.is_cuda and t.is_contiguous(), (t.dtype, t.device, t.stride())
+    if shape:
+        assert tuple(t.shape) == tuple(shape), (tuple(t.shape), shape)
+
+
+def bf16_linear_fwd(x, w16_ptr, b_ptr, N, relu=False, residual=None, drop_p=0.0, seed=0, seed_off=0, out16=True):
+    """y = residual + dropout(act(x w^T + b)): x [M, K] bf16, w [N, K] bf16; y bf16, or fp32 (always with a residual)"""
+    M, K = x.shape
+    _chk16(x)
+    out16 = bool(out16) and residual is None
+    y = torch.empty((M, N), dtype=BF16 if out16 else F32, device=x.device)
+    if residual is not None:
+        _chk(residual, M, N)
+    lib().bf16_linear_fwd(_p(x), w16_ptr, b_ptr, _p(y), int(out16), M, N, K, int(relu), _p(residual), float(drop_p), seed,
+                          seed_off, _stream())
+    return y
+
+
+def bf16_linear_dgrad(dy, w16_ptr, K, relu_mask_src=None, out16=True, out=None, accumulate=False):
+    """dx (+)= (dy w) * (mask > 0): dy [M, N] bf16, w [N, K] bf16; mask bf16 or fp32 [M, K]"""
+    M, N = dy.shape
+    _chk16(dy)
+    dx = out if out is not None else torch.empty((M, K), dtype=BF16 if out16 else F32, device=dy.device)
+    assert dx.dtype == (BF16 if out16 else F32) and tuple(dx.shape) == (M, K) and dx.is_contiguous()
+    mask16 = 0
+    if relu_mask_src is not None:
+        assert tuple(relu_mask_src.shape) == (M, K) and relu_mask_src.is_contiguous() and out16
+        mask16 = int(relu_mask_src.dtype == BF16)
+    lib().bf16_linear_dgrad(_p(dy), w16_ptr, _p(dx), int(out16), M, N, K, _p(relu_mask_src), mask16, int(accumulate), _stream())
+    return dx
+
+
+def bf16_linear_wgrad(x, dy, dw_ptr, ws: Workspace, accumulate=False, dbias_ptr=0):
+    """dw (fp32) (+)= dy^T x, dbias (+)= column sums of dy: x [M, K], dy [M, N] bf16"""
+    M, K = x.shape
+    M2, N = dy.shape
+    assert M == M2
+    _chk16(x)
+    _chk16(dy)
+    lib().bf16_linear_wgrad(_p(x), _p(dy), dw_ptr, dbias_ptr, M, N, K, int(accumulate), ws.ptr, ws.nbytes, _stream())
+
+
+def bf16_conv2d_fwd(x, w16_ptr, K, R, S, stride, pad, out16=True):
+    N, H, W, C = x.shape
+    _chk16(x)
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    y = torch.empty((N, Ho, Wo, K), dtype=BF16 if out16 else F32, device=x.device)
+    lib().bf16_conv2d_fwd(_p(x), w16_ptr, _p(y), int(out16), N, H, W, C, K, R, S, stride, pad, _stream())
+    return y
+
+
+def bf16_conv2d_dgrad(dy, w16_ptr, x_shape, R, S, stride, pad, out16=True, out=None, accumulate=False):
+    N, H, W, C = x_shape
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    K = dy.shape[3]
+    _chk16(dy, N, Ho, Wo, K)
+    dx = out if out is not None else torch.empty(x_shape, dtype=BF16 if out16 else F32, device=dy.device)
+    assert dx.dtype == (BF16 if out16 else F32) and tuple(dx.shape) == tuple(x_shape) and dx.is_contiguous()
+    lib().bf16_conv2d_dgrad(_p(dy), w16_ptr, _p(dx), int(out16), N, H, W, C, K, R, S, stride, pad, int(accumulate), _stream())
+    return dx
+
+
+def bf16_conv2d_wgrad(x, dy, dw_ptr, R, S, stride, pad, ws: Workspace, accumulate=False):
+    N, H, W, C = x.shape
+    _chk16(x)
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    K = dy.shape[3]
+    _chk16(dy, N, Ho, Wo, K)
+    lib().bf16_conv2d_wgrad(_p(x), _p(dy), dw_ptr, N, H, W, C, K, R, S, stride, pad, int(accumulate), ws.ptr, ws.nbytes, _stream())

@@ -97,6 +97,27 @@ int ds6g_linear_dgrad(const float* dy, const float* w, float* dx, int M, int N, 
 int ds6g_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, int M, int N, int K, int accumulate,
                       float* ws, size_t ws_bytes, void* stream);
 
+/* ---- bgemm.hip : the same Conv2d / Linear products on bf16-STORED operands (the bf16 configuration of BASELINE configs[1]
+ * and [4]: bf16 activations, a bf16 shadow of the weights refreshed by ds6g_adamw_step, fp32 accumulation; the reference has
+ * no mixed precision, train2_seq.py:111-116).  x / dy / w: bf16; y / dx: bf16 when out16 else fp32; dw / dbias / bias /
+ * residual: fp32.  Tiles travel HBM -> LDS as bf16 by LDS-DMA and feed v_mfma_f32_32x32x16_bf16 without conversion.
+ * Shape limits (every layer of the model but the 4-channel stems): the reduction channel count is a multiple of 64, the
+ * other a multiple of 8; dgrad: stride 1; wgrad: Wo % 64 == 0, or 64 % Wo == 0 with Ho % (64 / Wo) == 0, or a Linear. */
+int ds6g_bf16_conv2d_fwd(const void* x, const void* w, void* y, int out16, int N, int H, int W, int C, int K, int R, int S,
+                         int stride, int pad, void* stream);
+int ds6g_bf16_conv2d_dgrad(const void* dy, const void* w, void* dx, int out16, int N, int H, int W, int C, int K, int R,
+                           int S, int stride, int pad, int accumulate, void* stream);
+int ds6g_bf16_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
+                           int stride, int pad, int accumulate, float* ws, size_t ws_bytes, void* stream);
+/* nn.Linear of the GPT blocks (model2_seq.py:97-99,109,121-126,131-132) on bf16 operands; a fused residual add writes the
+ * fp32 residual stream (out16 must be 0 then); mask_src [M][K]: bf16 (mask16) or fp32, with a bf16 dx only. */
+int ds6g_bf16_linear_fwd(const void* x, const void* w, const float* bias, void* y, int out16, int M, int N, int K, int relu,
+                         const float* residual, float drop_p, uint64_t seed, uint64_t seed_off, void* stream);
+int ds6g_bf16_linear_dgrad(const void* dy, const void* w, void* dx, int out16, int M, int N, int K, const void* mask_src,
+                           int mask16, int accumulate, void* stream);
+int ds6g_bf16_linear_wgrad(const void* x, const void* dy, float* dw, float* dbias, int M, int N, int K, int accumulate,
+                           float* ws, size_t ws_bytes, void* stream);
+
 /* ---- norm.hip ----------------------------------------------------------------------------------
  * BatchNorm2d in train mode (+ReLU, +residual add of BasicBlock): torchvision BasicBlock via
  * model2_seq.py:496-497,501-502,506-507 and the layer calls above; eval mode uses running stats. */
