@@ -108,6 +108,11 @@ def cpu_baseline(batch=12, steps=3, warmup=1, small_batch=2, small_steps=10, sma
 def variant_name(v, dtype="f32", short=False):
     """variant code (include/ds6g.h): 10000 * wide + 1000 * epilogue + 100 * uniform-walk + 10 * mode + tile  ->  the
     template instantiation exactly as rocprofv3 names it: igemm_kernel<mode, BM, BN, epilogue, BK, bf16, walk>"""
+    if v >= 30000:  # bgemm.hip (bf16-stored operands): 30000 + 100 * bf16-output + 10 * mode + tile (0 = 128x128, 1 = 64x64)
+        o16, mode, tile = (v - 30000) // 100, (v - 30000) % 100 // 10, v % 10
+        t = ("128x128", "64x64")[tile]
+        return (f"bf16-stored/{MODE_NAMES[mode]}/{t}" + ("/bf16-out" if o16 else "")) if short else \
+            f"bgemm_kernel<{mode}, {t.split('x')[0]}, {t.split('x')[1]}, {o16}, *>"
     if v >= 20000:  # winograd.hip (flops recorded = those of the direct 3x3 conv it replaces)
         return ("winograd_fwd_kernel<1>", "winograd_wgrad_kernel")[v - 20000] if not short else \
             ("winograd/fwd+dgrad", "winograd/wgrad")[v - 20000]
@@ -139,29 +144,29 @@ def roofline_from_records(agg, dtype, traffic):
 
     def one(v):
         cnt, fl, ms = agg[v]
-        ex = WINOGRAD_EXEC if v >= 20000 else 1.0
+        ex = WINOGRAD_EXEC if 20000 <= v < 30000 else 1.0
         algo = fl / (ms * 1e-3) / 1e12
         return dict(kernel=variant_name(v, dtype), achieved=algo * ex, peak=peak, unit="TFLOP/s", frac=algo * ex / peak,
                     traffic=traffic(v) if dtype == "f32" else None, algorithmic_tflops=algo, launches_per_step=cnt,
                     avg_launch_us=ms * 1e3 / cnt, flops_per_launch=fl * ex / cnt, algorithmic_flops_per_launch=fl / cnt)
 
     roof = dict(bound="mfma", **one(dom))
-    if dom >= 20000:
+    if 20000 <= dom < 30000:
         roof["note"] = ("Winograd F(2x2,3x3): achieved / frac count the MFMA flops the kernel executes (2.25x fewer than the "
                         "direct 3x3 conv); algorithmic_tflops is the direct-conv rate, see DESIGN.md 3.1b")
-        direct = [v for v in agg if v < 20000]
+        direct = [v for v in agg if not 20000 <= v < 30000]
         if direct:
             d = one(max(direct, key=lambda v: agg[v][2]))
             d.pop("peak"), d.pop("unit")
             roof["largest_direct_kernel"] = d
     tot_ms = sum(v[2] for v in agg.values())
     tot_fl = sum(v[1] for v in agg.values())
-    tot_ex = sum(v[1] * (WINOGRAD_EXEC if k >= 20000 else 1.0) for k, v in agg.items())
+    tot_ex = sum(v[1] * (WINOGRAD_EXEC if 20000 <= k < 30000 else 1.0) for k, v in agg.items())
     roof["igemm_family"] = dict(achieved=tot_ex / (tot_ms * 1e-3) / 1e12, algorithmic_tflops=tot_fl / (tot_ms * 1e-3) / 1e12,
                                 ms_per_step=tot_ms, flops_per_step=tot_fl,
                                 by_variant={variant_name(v, dtype, short=True):
                                             dict(launches=a[0], ms=round(a[2], 3),
-                                                 tflops=round(a[1] * (WINOGRAD_EXEC if v >= 20000 else 1.0) / (a[2] * 1e-3) / 1e12, 2))
+                                                 tflops=round(a[1] * (WINOGRAD_EXEC if 20000 <= v < 30000 else 1.0) / (a[2] * 1e-3) / 1e12, 2))
                                             for v, a in sorted(agg.items())})
     return roof
 

@@ -54,6 +54,10 @@ struct AttnParams {
     float* hs;
     float* hp;
     int nkg;
+    // bf16-storage path: the final o (forward) / dq, dk, dv (backward) are GEMM operands and are written as bf16 (the
+    // split slabs and every kernel-internal tensor stay fp32); o16: the backward reads its forward output as bf16
+    int out16;
+    int o16;
 };
 
 __device__ __forceinline__ int krow16(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -245,6 +249,23 @@ __device__ __forceinline__ void mma_dims(f32x16* acc, unsigned tile, const f32x1
 
 // write an accumulator set acc[blk][16] = X^T[d][row] to global X[row][d] (row on the lane)
 template <int HD>
+__device__ __forceinline__ void store_rows16(const f32x16* acc, __bf16* base, int ld, int row, int T, int half, float mul) {
+    constexpr int NB = (HD + 31) / 32;
+    typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+    if (row >= T) return;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = blk * 32 + 8 * g + 4 * half;
+            if (d < HD)
+                *reinterpret_cast<bf16x4_*>(base + (long)row * ld + d) =
+                    bf16x4_{(__bf16)(acc[blk][4 * g] * mul), (__bf16)(acc[blk][4 * g + 1] * mul),
+                            (__bf16)(acc[blk][4 * g + 2] * mul), (__bf16)(acc[blk][4 * g + 3] * mul)};
+        }
+    }
+}
+template <int HD>
 __device__ __forceinline__ void store_rows(const f32x16* acc, float* base, int ld, int row, int T, int half, float mul) {
     constexpr int NB = (HD + 31) / 32;
     if (row >= T) return;
@@ -377,7 +398,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const float ltot = l + __shfl_xor(l, 32, 64);
     const long stat = (long)(b * p.nh + h) * T + q_row;
     if (p.splits == 1) {
-        store_rows<HD>(oacc, p.o + head_off, p.ld, q_row, T, half, 1.0f / ltot);
+        if (p.out16) store_rows16<HD>(oacc, reinterpret_cast<__bf16*>(p.o) + head_off, p.ld, q_row, T, half, 1.0f / ltot);
+        else store_rows<HD>(oacc, p.o + head_off, p.ld, q_row, T, half, 1.0f / ltot);
         if (half == 0 && q_row < T) p.lse[stat] = m + __logf(ltot);
     } else {
         store_rows<HD>(oacc, p.o + (size_t)split * p.slab + head_off, p.ld, q_row, T, half, 1.0f);
@@ -392,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 // o = sum_s o_s exp(m_s - m) / sum_s l_s exp(m_s - m); lse = m + log(...)
 __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(const float* __restrict__ part, const float* __restrict__ ml,
                                                              float* __restrict__ o, float* __restrict__ lse, int B, int T,
-                                                             int nh, int hd, int ld, int splits, size_t slab) {
+                                                             int nh, int hd, int ld, int splits, size_t slab, int out16) {
     const int c4n = nh * hd / 4;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * T * c4n) return;
@@ -412,7 +434,14 @@ __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(const float* __rest
         l += ml[(s * sstride + stat) * 2 + 1] * w;
         acc += w * *reinterpret_cast<const f32x4*>(part + (size_t)s * slab + row * ld + c4 * 4);
     }
-    *reinterpret_cast<f32x4*>(o + row * ld + c4 * 4) = acc * (1.0f / l);
+    acc = acc * (1.0f / l);
+    if (out16) {
+        typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<bf16x4_*>(reinterpret_cast<__bf16*>(o) + row * ld + c4 * 4) =
+            bf16x4_{(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
+    } else {
+        *reinterpret_cast<f32x4*>(o + row * ld + c4 * 4) = acc;
+    }
     if ((c4 * 4) % hd == 0) lse[stat] = m + __logf(l);
 }
 
@@ -486,7 +515,8 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
         step(Xa0, Xb0, Xa1, Xb1, kt, kt + 1 < t_end);
         if (kt + 1 < t_end) step(Xa1, Xb1, Xa0, Xb0, kt + 1, kt + 2 < t_end);
     }
-    if (p.splits == 1) store_rows<HD>(dq, p.dq + head_offd, p.ldd, q_row, T, half, 1.0f);
+    if (p.splits == 1 && p.out16) store_rows16<HD>(dq, reinterpret_cast<__bf16*>(p.dq) + head_offd, p.ldd, q_row, T, half, 1.0f);
+    else if (p.splits == 1) store_rows<HD>(dq, p.dq + head_offd, p.ldd, q_row, T, half, 1.0f);
     else store_rows<HD>(dq, p.dq + (size_t)split * p.slab + head_off, p.ld, q_row, T, half, 1.0f);
 }
 
@@ -595,7 +625,10 @@ __global__ __launch_bounds__(256, (HD <= 32 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
         step(Xa0, Xb0, Xa1, Xb1, qt, 0, qt + 1 < t_end);
         if (qt + 1 < t_end) step(Xa1, Xb1, Xa0, Xb0, qt + 1, 1, qt + 2 < t_end);
     }
-    if (p.splits == 1) {
+    if (p.splits == 1 && p.out16) {
+        if (DO_DK) store_rows16<HD>(dk, reinterpret_cast<__bf16*>(p.dk) + head_offd, p.ldd, key, T, half, 1.0f);
+        if (DO_DV) store_rows16<HD>(dv, reinterpret_cast<__bf16*>(p.dv) + head_offd, p.ldd, key, T, half, 1.0f);
+    } else if (p.splits == 1) {
         if (DO_DK) store_rows<HD>(dk, p.dk + head_offd, p.ldd, key, T, half, 1.0f);
         if (DO_DV) store_rows<HD>(dv, p.dv + head_offd, p.ldd, key, T, half, 1.0f);
     } else {
@@ -606,7 +639,8 @@ __global__ __launch_bounds__(256, (HD <= 32 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
 
 // delta[b][h][t] = sum_d dO[t][h*hd + d] * O[t][h*hd + d]  (hand-over path: the dK/dV kernel runs first and needs it)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o,
-                                                         float* __restrict__ delta, int B, int T, int nh, int hd, int ld) {
+                                                         float* __restrict__ delta, int B, int T, int nh, int hd, int ld,
+                                                         int o16) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * T * nh) return;
     const int h = (int)(i % nh);
@@ -614,6 +648,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
     const float* a = o + row * ld + h * hd;
     const float* g = d_o + row * ld + h * hd;
     float acc = 0.f;
+    if (o16) {
+        typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+        const __bf16* a16 = reinterpret_cast<const __bf16*>(o) + row * ld + h * hd;
+        for (int d = 0; d < hd; d += 4) {
+            const bf16x4_ x = *reinterpret_cast<const bf16x4_*>(a16 + d);
+            const f32x4 y = *reinterpret_cast<const f32x4*>(g + d);
+            acc += (float)x[0] * y[0] + (float)x[1] * y[1] + (float)x[2] * y[2] + (float)x[3] * y[3];
+        }
+    } else
     for (int d = 0; d < hd; d += 4) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(a + d), y = *reinterpret_cast<const f32x4*>(g + d);
         acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
@@ -682,7 +725,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const AttnParams p
         step(Xa0, Xa1, kt, kt + 1 < t_end);
         if (kt + 1 < t_end) step(Xa1, Xa0, kt + 1, kt + 2 < t_end);
     }
-    if (p.splits == 1) store_rows<HD>(dq, p.dq + head_offd, p.ldd, q_row, T, half, 1.0f);
+    if (p.splits == 1 && p.out16) store_rows16<HD>(dq, reinterpret_cast<__bf16*>(p.dq) + head_offd, p.ldd, q_row, T, half, 1.0f);
+    else if (p.splits == 1) store_rows<HD>(dq, p.dq + head_offd, p.ldd, q_row, T, half, 1.0f);
     else store_rows<HD>(dq, p.dq + (size_t)split * p.slab + head_off, p.ld, q_row, T, half, 1.0f);
 }
 
@@ -732,7 +776,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dv2_kernel(const AttnParams p
         step(Xb0, Xb1, qt, qt + 1 < t_end);
         if (qt + 1 < t_end) step(Xb1, Xb0, qt + 1, qt + 2 < t_end);
     }
-    if (p.splits == 1) store_rows<HD>(dv, p.dv + head_offd, p.ldd, key, T, half, 1.0f);
+    if (p.splits == 1 && p.out16) store_rows16<HD>(dv, reinterpret_cast<__bf16*>(p.dv) + head_offd, p.ldd, key, T, half, 1.0f);
+    else if (p.splits == 1) store_rows<HD>(dv, p.dv + head_offd, p.ldd, key, T, half, 1.0f);
     else store_rows<HD>(dv, p.dv + (size_t)split * p.slab + head_off, p.ld, key, T, half, 1.0f);
 }
 
@@ -740,7 +785,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dv2_kernel(const AttnParams p
 // blockIdx.y picks the (part, out) pair, so dK and dV are reduced by one launch.
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ part0, float* __restrict__ out0,
                                                        const float* __restrict__ part1, float* __restrict__ out1,
-                                                       long n4, int cols4, int ld_in, int ld_out, int splits, size_t slab) {
+                                                       long n4, int cols4, int ld_in, int ld_out, int splits, size_t slab,
+                                                       int out16) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     const float* part = blockIdx.y ? part1 : part0;
@@ -750,7 +796,13 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
     const float* src = part + row * ld_in + c;
     f32x4 s = *reinterpret_cast<const f32x4*>(src);
     for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(src + (size_t)k * slab);
-    *reinterpret_cast<f32x4*>(out + row * ld_out + c) = s;
+    if (out16) {
+        typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<bf16x4_*>(reinterpret_cast<__bf16*>(out) + row * ld_out + c) =
+            bf16x4_{(__bf16)s[0], (__bf16)s[1], (__bf16)s[2], (__bf16)s[3]};
+    } else {
+        *reinterpret_cast<f32x4*>(out + row * ld_out + c) = s;
+    }
 }
 
 // number of loop splits: fills the chip evenly.  cap = workgroups resident at once (256 CUs x per-CU residency)
@@ -828,9 +880,9 @@ size_t ds6g_attention_workspace_bytes(int B, int T, int nh, int hd, int ld) {
 }
 
 // o = dropout(softmax(q k^T / sqrt(hd))) v ; lse[b][h][t] = logsumexp of the scaled scores
-int ds6g_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int T, int nh,
-                       int hd, int ld_qkv, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
-                       size_t ws_bytes, void* stream) {
+static int attention_fwd_impl(const float* q, const float* k, const float* v, float* o, int out16, float* lse, int B, int T,
+                              int nh, int hd, int ld_qkv, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
+                              size_t ws_bytes, void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(q && k && v && o && lse && B > 0 && T > 0 && ld % 4 == 0 && ld >= nh * hd);
     DS6G_CHECK_ARG(ld_qkv % 4 == 0 && ld_qkv >= nh * hd && (size_t)B * T * ld_qkv * sizeof(float) < OOB_OFF);
@@ -854,22 +906,36 @@ int ds6g_attention_fwd(const float* q, const float* k, const float* v, float* o,
     splits = cdiv(ntiles, p.tiles_per_split);
     p.splits = splits;
     float* part = (float*)ws;
+    p.out16 = out16;
     p.o = splits == 1 ? o : part;
     p.ml = splits == 1 ? nullptr : part + (size_t)splits * slab;
     int rc = launch_hd<0>(p, hd, dim3(qblocks, nh * splits, B), st);
     if (rc || splits == 1) return rc;
     const long n = (long)B * T * (nh * hd / 4);
     hipLaunchKernelGGL(attn_fwd_merge_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, p.ml, o, lse, B, T, nh, hd, ld,
-                       splits, slab);
+                       splits, slab, out16);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }
 
-// gradients of the above; delta is a [B][nh][T] scratch (rowsum(dO*O)), written then read
-int ds6g_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
-                       const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int T, int nh, int hd,
-                       int ld_qkv, int ld, int ld_dqkv, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
+int ds6g_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int T, int nh,
+                       int hd, int ld_qkv, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
                        size_t ws_bytes, void* stream) {
+    return attention_fwd_impl(q, k, v, o, 0, lse, B, T, nh, hd, ld_qkv, ld, drop_p, seed, seed_off, ws, ws_bytes, stream);
+}
+// bf16-storage path: q / k / v fp32 (column blocks of the fused projection output), o written as bf16 [B*T][ld]
+int ds6g_attention_fwd_bf16out(const float* q, const float* k, const float* v, void* o, float* lse, int B, int T, int nh,
+                               int hd, int ld_qkv, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
+                               size_t ws_bytes, void* stream) {
+    return attention_fwd_impl(q, k, v, (float*)o, 1, lse, B, T, nh, hd, ld_qkv, ld, drop_p, seed, seed_off, ws, ws_bytes,
+                              stream);
+}
+
+// gradients of the above; delta is a [B][nh][T] scratch (rowsum(dO*O)), written then read
+static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, int o16, const float* d_o,
+                              const float* lse, float* delta, float* dq, float* dk, float* dv, int out16, int B, int T,
+                              int nh, int hd, int ld_qkv, int ld, int ld_dqkv, float drop_p, uint64_t seed,
+                              uint64_t seed_off, void* ws, size_t ws_bytes, void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(q && k && v && o && d_o && lse && delta && dq && dk && dv && ld % 4 == 0 && ld >= nh * hd);
     DS6G_CHECK_ARG(ld_qkv % 4 == 0 && ld_qkv >= nh * hd && (size_t)B * T * ld_qkv * sizeof(float) < OOB_OFF);
@@ -880,6 +946,7 @@ int ds6g_attention_bwd(const float* q, const float* k, const float* v, const flo
     AttnParams p{};
     p.q = q; p.k = k; p.v = v; p.o = const_cast<float*>(o); p.lse = const_cast<float*>(lse); p.d_o = d_o;
     p.delta = delta; p.T = T; p.nh = nh; p.B = B; p.ld = ld; p.ldq = ld_qkv; p.ldd = ld_dqkv;
+    p.out16 = out16; p.o16 = o16;
     p.bytes = (unsigned)(slab * sizeof(float)); p.slab = slab;
     p.bytes_q = (unsigned)((((size_t)B * T - 1) * ld_qkv + nh * hd) * sizeof(float));
     p.scale = 1.0f / sqrtf((float)hd);
@@ -897,7 +964,7 @@ int ds6g_attention_bwd(const float* q, const float* k, const float* v, const flo
         float* wsf = (float*)((char*)ws + hand);
         const size_t wsb = ws_bytes - hand;
         hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((long)B * T * nh, 256)), dim3(256), 0, st, o, d_o, delta, B, T, nh,
-                           hd, ld);
+                           hd, ld, o16);
         DS6G_LAUNCH_CHECK();
         auto plan = [&](int per_cu, size_t slabs_per_split) {
             const size_t cap = wsb / (slabs_per_split * slab * sizeof(float));
@@ -914,7 +981,7 @@ int ds6g_attention_bwd(const float* q, const float* k, const float* v, const flo
         if (rc) return rc;
         if (p.splits > 1) {
             hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256), two_pass ? 1 : 2), dim3(256), 0, st, (const float*)wsf, dk,
-                               (const float*)(wsf + (size_t)p.splits * slab), dv, n4, cols4, ld, ld_dqkv, p.splits, slab);
+                               (const float*)(wsf + (size_t)p.splits * slab), dv, n4, cols4, ld, ld_dqkv, p.splits, slab, out16);
             DS6G_LAUNCH_CHECK();
         }
         if (two_pass) {
@@ -924,7 +991,7 @@ int ds6g_attention_bwd(const float* q, const float* k, const float* v, const flo
             if (rc) return rc;
             if (p.splits > 1) {
                 hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256), 1), dim3(256), 0, st, (const float*)wsf, dv,
-                                   (const float*)nullptr, (float*)nullptr, n4, cols4, ld, ld_dqkv, p.splits, slab);
+                                   (const float*)nullptr, (float*)nullptr, n4, cols4, ld, ld_dqkv, p.splits, slab, out16);
                 DS6G_LAUNCH_CHECK();
             }
         }
@@ -934,11 +1001,13 @@ int ds6g_attention_bwd(const float* q, const float* k, const float* v, const flo
         if (rc) return rc;
         if (p.splits > 1) {
             hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256), 1), dim3(256), 0, st, (const float*)wsf, dq,
-                               (const float*)nullptr, (float*)nullptr, n4, cols4, ld, ld_dqkv, p.splits, slab);
+                               (const float*)nullptr, (float*)nullptr, n4, cols4, ld, ld_dqkv, p.splits, slab, out16);
             DS6G_LAUNCH_CHECK();
         }
         return DS6G_OK;
     }
+    // the recomputing form reads o inside its dQ kernel (fp32 only): the bf16-storage path needs the hand-over workspace
+    DS6G_CHECK_ARG(!o16);
     // ---- dQ (split over keys)
     {
         const size_t max_by_ws = ws ? ws_bytes / (slab * sizeof(float)) : 1;
@@ -952,7 +1021,7 @@ int ds6g_attention_bwd(const float* q, const float* k, const float* v, const flo
         if (rc) return rc;
         if (splits > 1) {
             hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256), 1), dim3(256), 0, st, (const float*)ws, dq,
-                               (const float*)nullptr, (float*)nullptr, n4, cols4, ld, ld_dqkv, splits, slab);
+                               (const float*)nullptr, (float*)nullptr, n4, cols4, ld, ld_dqkv, splits, slab, out16);
             DS6G_LAUNCH_CHECK();
         }
     }
@@ -970,11 +1039,28 @@ int ds6g_attention_bwd(const float* q, const float* k, const float* v, const flo
         if (rc) return rc;
         if (splits > 1) {
             hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256), 2), dim3(256), 0, st, (const float*)wsf, dk,
-                               (const float*)(wsf + (size_t)splits * slab), dv, n4, cols4, ld, ld_dqkv, splits, slab);
+                               (const float*)(wsf + (size_t)splits * slab), dv, n4, cols4, ld, ld_dqkv, splits, slab, out16);
             DS6G_LAUNCH_CHECK();
         }
     }
     return DS6G_OK;
+}
+
+int ds6g_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                       const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int T, int nh, int hd,
+                       int ld_qkv, int ld, int ld_dqkv, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
+                       size_t ws_bytes, void* stream) {
+    return attention_bwd_impl(q, k, v, o, 0, d_o, lse, delta, dq, dk, dv, 0, B, T, nh, hd, ld_qkv, ld, ld_dqkv, drop_p, seed,
+                              seed_off, ws, ws_bytes, stream);
+}
+// bf16-storage path: o (the forward output) is bf16, dq / dk / dv are written as bf16 [B*T][ld_dqkv]; q / k / v / d_o fp32.
+// Needs the full ds6g_attention_workspace_bytes (hand-over form).
+int ds6g_attention_bwd_bf16(const float* q, const float* k, const float* v, const void* o, const float* d_o,
+                            const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int T, int nh, int hd,
+                            int ld_qkv, int ld, int ld_dqkv, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
+                            size_t ws_bytes, void* stream) {
+    return attention_bwd_impl(q, k, v, (const float*)o, 1, d_o, lse, delta, (float*)dq, (float*)dk, (float*)dv, 1, B, T, nh, hd,
+                              ld_qkv, ld, ld_dqkv, drop_p, seed, seed_off, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -219,6 +219,8 @@ int bn_geometry(long M, int C, int* rows_per_block, int* nblk) {
 // ------------------------------------ LayerNorm ----------------------------------------------
 // one wave per row; a lane owns columns 4*lane + 256*j + {0..3} (16-B accesses) when C >= 256, else the
 // scalar columns lane + 64*j.  C in {64,128,256,512}.
+typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+
 template <int C>
 struct LnRow {
     static constexpr bool VEC = C >= 256;
@@ -247,11 +249,35 @@ struct LnRow {
         }
     }
     __device__ static int col(int e, int lane) { return VEC ? 4 * lane + 256 * (e >> 2) + (e & 3) : lane + 64 * e; }
+    // bf16 rows (the bf16-storage path: GEMM-facing tensors are bf16, the arithmetic here stays fp32), same column map
+    __device__ static void load(float* v, const __bf16* row, int lane) {
+        if (VEC) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const bf16x4_ t = *reinterpret_cast<const bf16x4_*>(row + 4 * lane + 256 * j);
+                v[4 * j] = (float)t[0]; v[4 * j + 1] = (float)t[1]; v[4 * j + 2] = (float)t[2]; v[4 * j + 3] = (float)t[3];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] = (float)row[lane + 64 * j];
+        }
+    }
+    __device__ static void store(const float* v, __bf16* row, int lane) {
+        if (VEC) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                *reinterpret_cast<bf16x4_*>(row + 4 * lane + 256 * j) =
+                    bf16x4_{(__bf16)v[4 * j], (__bf16)v[4 * j + 1], (__bf16)v[4 * j + 2], (__bf16)v[4 * j + 3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) row[lane + 64 * j] = (__bf16)v[j];
+        }
+    }
 };
 
-template <int C>
+template <int C, typename TY>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     const float* __restrict__ beta, TY* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M,
                                                      float eps) {
     using R = LnRow<C>;
@@ -284,12 +310,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 constexpr int LN_BWD_ROWS = 16;  // rows per block (4 per wave): >= 700 blocks at M = 11544
 
-template <int C>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int C, typename TDY, typename TDD>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ add,
                                                      float* __restrict__ dx, float* __restrict__ partial, int M,
-                                                     float* __restrict__ dx_drop, uint32_t thr, float dscale,
+                                                     TDD* __restrict__ dx_drop, uint32_t thr, float dscale,
                                                      uint64_t seed, uint64_t seed_off) {
     using R = LnRow<C>;
     __shared__ float red[4][2][C];
@@ -411,6 +437,51 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ 
 
 }  // namespace
 
+extern "C" size_t ds6g_layernorm_bwd_workspace_bytes(int M, int C);
+
+template <typename TY>
+static int ln_fwd_launch(const float* x, const float* gamma, const float* beta, TY* y, float* mean, float* rstd, int M, int C,
+                         float eps, hipStream_t st) {
+    dim3 grid(cdiv(M, 4)), block(256);
+    switch (C / 64) {
+        case 1: hipLaunchKernelGGL((ln_fwd_kernel<64, TY>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
+        case 2: hipLaunchKernelGGL((ln_fwd_kernel<128, TY>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
+        case 4: hipLaunchKernelGGL((ln_fwd_kernel<256, TY>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
+        case 8: hipLaunchKernelGGL((ln_fwd_kernel<512, TY>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
+        default: DS6G_CHECK_ARG(!"LayerNorm width must be 64/128/256/512");
+    }
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+template <typename TDY, typename TDD>
+static int ln_bwd_launch(const TDY* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                         const float* add, float* dx, float* dgamma, float* dbeta, int M, int C, int accumulate_param_grads,
+                         TDD* dx_drop, float drop_p, uint64_t seed, uint64_t seed_off, void* ws, size_t ws_bytes,
+                         hipStream_t st) {
+    DS6G_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws);
+    DS6G_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
+    const uint32_t thr = ds6g_drop_threshold(drop_p);
+    const float dscale = 1.f / (1.f - drop_p);
+    DS6G_CHECK_ARG(C % 64 == 0 && C <= 512);
+    DS6G_CHECK_ARG(ws_bytes >= ds6g_layernorm_bwd_workspace_bytes(M, C));
+    const int nblk = cdiv(M, LN_BWD_ROWS);
+    float* partial = (float*)ws;
+    dim3 grid(nblk), block(256);
+    switch (C / 64) {
+        case 1: hipLaunchKernelGGL((ln_bwd_kernel<64, TDY, TDD>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off); break;
+        case 2: hipLaunchKernelGGL((ln_bwd_kernel<128, TDY, TDD>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off); break;
+        case 4: hipLaunchKernelGGL((ln_bwd_kernel<256, TDY, TDD>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off); break;
+        case 8: hipLaunchKernelGGL((ln_bwd_kernel<512, TDY, TDD>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off); break;
+        default: DS6G_CHECK_ARG(!"LayerNorm width must be 64/128/256/512");
+    }
+    DS6G_LAUNCH_CHECK();
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(cdiv(2 * C, FIN_COLS)), dim3(256), 0, st, partial, nblk, 2 * C, dgamma,
+                       dbeta, C, accumulate_param_grads);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
 extern "C" {
 
 size_t ds6g_bn_workspace_bytes(long M, int C) {
@@ -518,17 +589,16 @@ int ds6g_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
     DS6G_ENTER();
     DS6G_CHECK_ARG(x && gamma && beta && y && mean && rstd && M > 0);
     DS6G_CHECK_ARG(C % 64 == 0 && C <= 512);
-    dim3 grid(cdiv(M, 4)), block(256);
-    hipStream_t st = (hipStream_t)stream;
-    switch (C / 64) {
-        case 1: hipLaunchKernelGGL((ln_fwd_kernel<64>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
-        case 2: hipLaunchKernelGGL((ln_fwd_kernel<128>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
-        case 4: hipLaunchKernelGGL((ln_fwd_kernel<256>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
-        case 8: hipLaunchKernelGGL((ln_fwd_kernel<512>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
-        default: DS6G_CHECK_ARG(!"LayerNorm width must be 64/128/256/512");
-    }
-    DS6G_LAUNCH_CHECK();
-    return DS6G_OK;
+    return ln_fwd_launch<float>(x, gamma, beta, y, mean, rstd, M, C, eps, (hipStream_t)stream);
+}
+
+// bf16-storage path: the normalised rows feed a GEMM and are written as bf16 (statistics and arithmetic fp32)
+int ds6g_layernorm_fwd_bf16out(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                               int M, int C, float eps, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && gamma && beta && y && mean && rstd && M > 0);
+    DS6G_CHECK_ARG(C % 64 == 0 && C <= 512);
+    return ln_fwd_launch<__bf16>(x, gamma, beta, (__bf16*)y, mean, rstd, M, C, eps, (hipStream_t)stream);
 }
 
 size_t ds6g_layernorm_bwd_workspace_bytes(int M, int C) { return (size_t)cdiv(M, LN_BWD_ROWS) * 2 * C * sizeof(float); }
@@ -539,28 +609,24 @@ int ds6g_layernorm_bwd(const float* dy, const float* x, const float* mean, const
                        int accumulate_param_grads, float* dx_drop, float drop_p, uint64_t seed, uint64_t seed_off,
                        void* ws, size_t ws_bytes, void* stream) {
     DS6G_ENTER();
-    DS6G_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws);
-    DS6G_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
-    const uint32_t thr = ds6g_drop_threshold(drop_p);
-    const float dscale = 1.f / (1.f - drop_p);
-    DS6G_CHECK_ARG(C % 64 == 0 && C <= 512);
-    DS6G_CHECK_ARG(ws_bytes >= ds6g_layernorm_bwd_workspace_bytes(M, C));
-    const int nblk = cdiv(M, LN_BWD_ROWS);
-    float* partial = (float*)ws;
-    dim3 grid(nblk), block(256);
-    hipStream_t st = (hipStream_t)stream;
-    switch (C / 64) {
-        case 1: hipLaunchKernelGGL((ln_bwd_kernel<64>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off); break;
-        case 2: hipLaunchKernelGGL((ln_bwd_kernel<128>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off); break;
-        case 4: hipLaunchKernelGGL((ln_bwd_kernel<256>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off); break;
-        case 8: hipLaunchKernelGGL((ln_bwd_kernel<512>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off); break;
-        default: DS6G_CHECK_ARG(!"LayerNorm width must be 64/128/256/512");
-    }
-    DS6G_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_finalize_kernel, dim3(cdiv(2 * C, FIN_COLS)), dim3(256), 0, st, partial, nblk, 2 * C, dgamma,
-                       dbeta, C, accumulate_param_grads);
-    DS6G_LAUNCH_CHECK();
-    return DS6G_OK;
+    return ln_bwd_launch<float, float>(dy, x, mean, rstd, gamma, add, dx, dgamma, dbeta, M, C, accumulate_param_grads, dx_drop,
+                                       drop_p, seed, seed_off, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// bf16-storage path: dy is a GEMM output stored as bf16 (dy16) or fp32; dx (the residual-stream gradient) stays fp32;
+// dx_drop (nullable) = dropout(dx) is the next GEMM's operand and is written as bf16 (with drop_p = 0: a bf16 copy of dx)
+int ds6g_layernorm_bwd_bf16(const void* dy, int dy16, const float* x, const float* mean, const float* rstd,
+                            const float* gamma, const float* add, float* dx, float* dgamma, float* dbeta, int M, int C,
+                            int accumulate_param_grads, void* dx_drop, float drop_p, uint64_t seed, uint64_t seed_off,
+                            void* ws, size_t ws_bytes, void* stream) {
+    DS6G_ENTER();
+    if (dy16)
+        return ln_bwd_launch<__bf16, __bf16>((const __bf16*)dy, x, mean, rstd, gamma, add, dx, dgamma, dbeta, M, C,
+                                             accumulate_param_grads, (__bf16*)dx_drop, drop_p, seed, seed_off, ws, ws_bytes,
+                                             (hipStream_t)stream);
+    return ln_bwd_launch<float, __bf16>((const float*)dy, x, mean, rstd, gamma, add, dx, dgamma, dbeta, M, C,
+                                        accumulate_param_grads, (__bf16*)dx_drop, drop_p, seed, seed_off, ws, ws_bytes,
+                                        (hipStream_t)stream);
 }
 
 constexpr int COLSUM_ROWS = 32;

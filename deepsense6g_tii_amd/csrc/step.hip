@@ -114,6 +114,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// dst[i] = bf16(src[i]) (RNE): the bf16 shadow of the parameter arena, refreshed once per training forward of the
+// bf16-storage path (fp32 master weights stay in the arena)
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n4) {
+    typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i * 4);
+        *reinterpret_cast<bf16x4_*>(dst + i * 4) = bf16x4_{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    }
+}
+
 // y[m][n] = act( sum_k x[row(m)][k] w[n][k] + b[n] ), row(m) = (m / rpg) * gstride + (m % rpg) * K
 __global__ void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                         const float* __restrict__ b, float* __restrict__ y, int M, int N, int K,
@@ -268,7 +278,18 @@ int ds6g_small_linear_bwd(const float* dy, const float* y_mask, const float* x, 
     return DS6G_OK;
 }
 
-int ds6g_version(void) { return 1; }
+// dst (bf16) = src (fp32), n % 4 == 0, both 8-byte aligned
+int ds6g_cast_f32_bf16(const float* src, void* dst, long n, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(src && dst && n > 0 && n % 4 == 0);
+    const long n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n4);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+int ds6g_version(void) { return 2; }
 
 int ds6g_set_compute_mode(int mode) {
     if (mode < 0 || mode > 3) return DS6G_ERR_ARG;

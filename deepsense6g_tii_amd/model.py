@@ -222,6 +222,13 @@ class TransFuser(nn.Module):
         self.use_winograd = True  # 3x3 / stride-1 convs (forward and data gradient) as Winograd F(2x2, 3x3) in fp32 mode
         self.fold_bn_eval = True  # eval(): BatchNorm folded into the conv weights (no BN kernels at inference)
         self.fuse_qkv = True      # key|query|value projections as one GEMM when their parameters are contiguous (arena)
+        # bf16 matrix-core mode ("bf16 forward/backward", BASELINE configs[1] / [4]): GEMM operands of the GPT stages are
+        # STORED as bf16 (LayerNorm outputs, attention output, MLP hidden, their gradients, a bf16 shadow of the weights
+        # refreshed once per forward; csrc/bgemm.hip) instead of fp32 tiles rounded on the way into the MFMA.  fp32 stay: the
+        # master weights, the residual stream, LayerNorm / softmax statistics, every accumulator, loss, optimizer.
+        self.bf16_storage = True
+        self._arena16 = None
+        self._use16 = False
         self._anchor = None
         self._arena = None
         if self.device.type == "cuda":
@@ -398,6 +405,22 @@ class TransFuser(nn.Module):
     def _g(self, p):
         """(grad pointer, accumulate flag) of parameter p for the backward walk in flight."""
         return self._gmode[id(p)]
+
+    def _w16(self, p):
+        """device pointer of parameter p inside the bf16 shadow of the parameter arena (same layout, 2-byte elements)"""
+        return self._arena16.data_ptr() + 2 * self._pslice[self._pname[id(p)]][0]
+
+    def _refresh_shadow16(self):
+        """bf16 shadow of the fp32 master weights, refreshed once per forward of the bf16-storage path: one streaming cast
+        over the arena (0.47 GB of traffic, ~0.1 ms: 0.3 % of a step), so it can never be stale whatever touched the
+        parameters (optimizer, load_state_dict, in-place edits).  Off when the parameters were re-pointed away from the
+        arena (EMA shadow applied): the fp32-storage kernels then run, reading the live pointers."""
+        self._use16 = bool(self.bf16_storage and self._arena is not None and lib().get_compute_mode() == 1
+                           and self.fuse_qkv and self.params_in_arena())
+        if self._use16:
+            if self._arena16 is None:
+                self._arena16 = torch.empty(self._arena.numel(), dtype=torch.bfloat16, device=self.device)
+            ops.cast_bf16(self._arena, out=self._arena16)
 
     def _begin_backward(self):
         # .grad is None -> write fresh and attach the arena view; .grad is our view -> accumulate in
@@ -661,7 +684,69 @@ class TransFuser(nn.Module):
         out = ops.bn_apply(c2, stats[0], stats[1], self._w(bn2.weight), self._w(bn2.bias), True, idn)
         return out, (x, c1, a1, s1, c2, (stats[0], stats[1]), cd, sd, out, ud1, ud2)
 
+    def _gpt_block_fwd16(self, blk, x, B, T, train):
+        """_gpt_block_fwd on bf16-stored GEMM operands: LN -> h (bf16) -> fused k|q|v GEMM (fp32 out: the attention kernels
+        stage fp32 tiles) -> attention (o written as bf16) -> proj GEMM + dropout + residual (fp32 stream) -> LN -> h2 (bf16)
+        -> fc1 + ReLU (bf16) -> fc2 + dropout + residual (fp32).  Same dropout counters / masks as the fp32-storage path."""
+        cfg = self.config
+        C = x.shape[1]
+        nh = cfg.n_head
+        pa = cfg.attn_pdrop if train else 0.0
+        pr = cfg.resid_pdrop if train else 0.0
+        at = blk.attn
+        h, m1, r1 = ops.layernorm_fwd_bf16(x, self._w(blk.ln1.weight), self._w(blk.ln1.bias), blk.ln1.eps)
+        kqv = ops.bf16_linear_fwd(h, self._w16(at.key.weight), self._w(at.key.bias), 3 * C, out16=False)
+        k, q, v = kqv[:, :C], kqv[:, C:2 * C], kqv[:, 2 * C:]
+        off_a = self._next_drop(B * nh * T * T) if pa > 0 else 0
+        y, lse = ops.attention_fwd_bf16out(q, k, v, B, T, nh, self._ws, pa, self._seed, off_a)
+        off_p = self._next_drop(x.numel()) if pr > 0 else 0
+        x1 = ops.bf16_linear_fwd(y, self._w16(at.proj.weight), self._w(at.proj.bias), C, residual=x, drop_p=pr,
+                                 seed=self._seed, seed_off=off_p)
+        h2, m2, r2 = ops.layernorm_fwd_bf16(x1, self._w(blk.ln2.weight), self._w(blk.ln2.bias), blk.ln2.eps)
+        fc1, fc2 = blk.mlp[0], blk.mlp[2]
+        f1 = ops.bf16_linear_fwd(h2, self._w16(fc1.weight), self._w(fc1.bias), fc1.out_features, relu=True)
+        off_m = self._next_drop(x.numel()) if pr > 0 else 0
+        x2 = ops.bf16_linear_fwd(f1, self._w16(fc2.weight), self._w(fc2.bias), C, residual=x1, drop_p=pr, seed=self._seed,
+                                 seed_off=off_m)
+        return x2, (x, h, m1, r1, q, k, v, y, lse, off_a, pa, off_p, pr, x1, h2, m2, r2, f1, off_m)
+
+    def _gpt_block_bwd16(self, blk, ctx, dx2, B, T, dz2, next_drop=None, want_dz=True):
+        """backward of _gpt_block_fwd16.  dx2: fp32 gradient of the block output (residual stream); dz2: dropout(dx2) as
+        bf16 (emitted by the LayerNorm backward above); returns (dx fp32, dropout(dx) as bf16 on the next block's mask)."""
+        (x, h, m1, r1, q, k, v, y, lse, off_a, pa, off_p, pr, x1, h2, m2, r2, f1, off_m) = ctx
+        C = x.shape[1]
+        nh = self.config.n_head
+        at = blk.attn
+        fc1, fc2 = blk.mlp[0], blk.mlp[2]
+
+        def wgrad(lin_w, lin_b, xin, dyin):
+            gw, aw = self._g(lin_w)
+            gb, _ = self._g(lin_b)
+            self._wg_launch(lambda: ops.bf16_linear_wgrad(xin, dyin, gw, self._ws, accumulate=bool(aw), dbias_ptr=gb), (xin, dyin))
+
+        wgrad(fc2.weight, fc2.bias, f1, dz2)
+        df1 = ops.bf16_linear_dgrad(dz2, self._w16(fc2.weight), fc1.out_features, relu_mask_src=f1)
+        wgrad(fc1.weight, fc1.bias, h2, df1)
+        dh2 = ops.bf16_linear_dgrad(df1, self._w16(fc1.weight), C)
+        g2w, a2 = self._g(blk.ln2.weight)
+        g2b, _ = self._g(blk.ln2.bias)
+        dx1, dz1 = ops.layernorm_bwd_bf16(dh2, x1, m2, r2, self._w(blk.ln2.weight), g2w, g2b, self._ws, add=dx2,
+                                          accumulate=bool(a2), drop=(pr, self._seed, off_p))
+        wgrad(at.proj.weight, at.proj.bias, y, dz1)
+        dy = ops.bf16_linear_dgrad(dz1, self._w16(at.proj.weight), C, out16=False)   # fp32: the attention backward's dO
+        dkqv = torch.empty((dy.shape[0], 3 * C), dtype=torch.bfloat16, device=dy.device)
+        ops.attention_bwd_bf16(q, k, v, y, dy, lse, B, T, nh, self._attn_ws(B, T, nh, C), pa, self._seed, off_a,
+                               out=(dkqv[:, C:2 * C], dkqv[:, :C], dkqv[:, 2 * C:]))
+        wgrad(at.key.weight, at.key.bias, h, dkqv)   # the fused [3C, C] block and its [3C] bias start at key.*
+        dh = ops.bf16_linear_dgrad(dkqv, self._w16(at.key.weight), C)
+        g1w, a1 = self._g(blk.ln1.weight)
+        g1b, _ = self._g(blk.ln1.bias)
+        return ops.layernorm_bwd_bf16(dh, x, m1, r1, self._w(blk.ln1.weight), g1w, g1b, self._ws, add=dx1,
+                                      accumulate=bool(a1), drop=next_drop, want_drop=want_dz)
+
     def _gpt_block_fwd(self, blk, x, B, T, train):
+        if self._use16:
+            return self._gpt_block_fwd16(blk, x, B, T, train)
         cfg = self.config
         C = x.shape[1]
         nh = cfg.n_head
@@ -740,6 +825,7 @@ class TransFuser(nn.Module):
         train = self.training
         self._fold_now = self.fold_bn_eval and not train and not record  # inference only: backward needs the BN tape
         self._recording = bool(record)
+        self._refresh_shadow16()
         S = cfg.seq_len
         if torch.is_tensor(lidars):
             B = lidars.shape[0] // S
@@ -980,10 +1066,18 @@ class TransFuser(nn.Module):
         gfb, _ = self._g(gpt.ln_f.bias)
         rev = list(zip(reversed(list(gpt.blocks)), reversed(blk_ctx)))
         drops = [(bc[12], self._seed, bc[18]) for _, bc in rev]  # (resid_pdrop, seed, fc2-branch mask offset) per block
-        dx, dz = ops.layernorm_bwd(dxo, x_last, mf, rf, self._w(gpt.ln_f.weight), gfw, gfb, self._ws,
-                                   accumulate=bool(af), drop=drops[0])
-        for i, (blk, bc) in enumerate(rev):
-            dx, dz = self._gpt_block_bwd(blk, bc, dx, B, T, dz2=dz, next_drop=drops[i + 1] if i + 1 < len(rev) else None)
+        if blk_ctx and blk_ctx[0][1].dtype == torch.bfloat16:   # recorded on the bf16-storage path
+            dx, dz = ops.layernorm_bwd_bf16(dxo, x_last, mf, rf, self._w(gpt.ln_f.weight), gfw, gfb, self._ws,
+                                            accumulate=bool(af), drop=drops[0])
+            for i, (blk, bc) in enumerate(rev):
+                last = i + 1 == len(rev)
+                dx, dz = self._gpt_block_bwd16(blk, bc, dx, B, T, dz, next_drop=None if last else drops[i + 1],
+                                               want_dz=not last)
+        else:
+            dx, dz = ops.layernorm_bwd(dxo, x_last, mf, rf, self._w(gpt.ln_f.weight), gfw, gfb, self._ws,
+                                       accumulate=bool(af), drop=drops[0])
+            for i, (blk, bc) in enumerate(rev):
+                dx, dz = self._gpt_block_bwd(blk, bc, dx, B, T, dz2=dz, next_drop=drops[i + 1] if i + 1 < len(rev) else None)
         self._wg_join()
         dpre = ops.dropout(dx, pe, self._seed, off_e) if pe > 0 else dx
         gpos, apos = self._g(gpt.pos_emb)

@@ -425,3 +425,75 @@ def bf16_conv2d_wgrad(x, dy, dw_ptr, R, S, stride, pad, ws: Workspace, accumulat
     K = dy.shape[3]
     _chk16(dy, N, Ho, Wo, K)
     lib().bf16_conv2d_wgrad(_p(x), _p(dy), dw_ptr, N, H, W, C, K, R, S, stride, pad, int(accumulate), ws.ptr, ws.nbytes, _stream())
+
+
+def cast_bf16(src, out=None):
+    """bf16 copy (RNE) of a contiguous fp32 tensor whose numel is a multiple of 4"""
+    _chk(src)
+    dst = out if out is not None else torch.empty(src.shape, dtype=BF16, device=src.device)
+    assert dst.dtype == BF16 and dst.numel() == src.numel() and dst.is_contiguous()
+    lib().cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream())
+    return dst
+
+
+def layernorm_fwd_bf16(x, gamma_ptr, beta_ptr, eps=1e-5):
+    """LayerNorm of fp32 rows, output written as bf16 (a GEMM operand) -> (y16, mean, rstd)"""
+    M, C = x.shape
+    _chk(x)
+    y = torch.empty((M, C), dtype=BF16, device=x.device)
+    mean = torch.empty(M, dtype=F32, device=x.device)
+    rstd = torch.empty(M, dtype=F32, device=x.device)
+    lib().layernorm_fwd_bf16out(_p(x), gamma_ptr, beta_ptr, _p(y), _p(mean), _p(rstd), M, C, eps, _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd_bf16(dy, x, mean, rstd, gamma_ptr, dgamma_ptr, dbeta_ptr, ws: Workspace, add=None, accumulate=False,
+                       drop=None, want_drop=True):
+    """dy bf16 or fp32 -> (dx fp32, dropout(dx) as bf16); drop = (p, seed, seed_off) or None (= plain bf16 copy of dx);
+    want_drop False: no second output (-> (dx, None))"""
+    M, C = x.shape
+    assert tuple(dy.shape) == (M, C) and dy.is_contiguous() and dy.dtype in (BF16, F32)
+    _chk(x)
+    if add is not None:
+        _chk(add, M, C)
+    dx = torch.empty_like(x)
+    dxd = torch.empty((M, C), dtype=BF16, device=x.device) if want_drop else None
+    p, seed, off = drop if drop is not None else (0.0, 0, 0)
+    lib().layernorm_bwd_bf16(_p(dy), int(dy.dtype == BF16), _p(x), _p(mean), _p(rstd), gamma_ptr, _p(add), _p(dx), dgamma_ptr,
+                             dbeta_ptr, M, C, int(accumulate), _p(dxd), float(p), seed, off, ws.ptr, ws.nbytes, _stream())
+    return dx, dxd
+
+
+def attention_fwd_bf16out(q, k, v, B, T, nh, ws: Workspace, drop_p=0.0, seed=0, seed_off=0):
+    """as attention_fwd, the output written as bf16 (operand of the projection GEMM)"""
+    M, C = q.shape
+    assert M == B * T
+    ldq = _rows(q, M, C)
+    assert _rows(k, M, C) == ldq and _rows(v, M, C) == ldq
+    o = torch.empty((M, C), dtype=BF16, device=q.device)
+    lse = torch.empty((B, nh, T), dtype=F32, device=q.device)
+    lib().attention_fwd_bf16out(_p(q), _p(k), _p(v), _p(o), _p(lse), B, T, nh, C // nh, ldq, C, float(drop_p), seed, seed_off,
+                                ws.ptr, ws.nbytes, _stream())
+    return o, lse
+
+
+def attention_bwd_bf16(q, k, v, o16, d_o, lse, B, T, nh, ws: Workspace, drop_p=0.0, seed=0, seed_off=0, out=None):
+    """o16: the bf16 forward output; d_o fp32; -> dq, dk, dv as bf16 (`out`: three [B*T, C] bf16 views of one row stride)"""
+    M, C = q.shape
+    ldq = _rows(q, M, C)
+    assert _rows(k, M, C) == ldq and _rows(v, M, C) == ldq
+    _chk16(o16, M, C)
+    _chk(d_o, M, C)
+    _chk(lse, B, nh, T)
+    assert ws.nbytes >= int(lib().attention_workspace_bytes(B, T, nh, C // nh, C)), "attention_bwd_bf16 needs the hand-over workspace"
+    delta = torch.empty_like(lse)
+    if out is None:
+        out = tuple(torch.empty((M, C), dtype=BF16, device=q.device) for _ in range(3))
+    dq, dk, dv = out
+    for t in out:
+        assert t.dtype == BF16 and tuple(t.shape) == (M, C) and t.stride(1) == 1 and t.stride(0) % 4 == 0
+    ldd = dq.stride(0)
+    assert dk.stride(0) == ldd and dv.stride(0) == ldd
+    lib().attention_bwd_bf16(_p(q), _p(k), _p(v), _p(o16), _p(d_o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, T, nh,
+                             C // nh, ldq, C, ldd, float(drop_p), seed, seed_off, ws.ptr, ws.nbytes, _stream())
+    return dq, dk, dv

@@ -144,6 +144,15 @@ int ds6g_layernorm_bwd(const float* dy, const float* x, const float* mean, const
                        const float* add, float* dx, float* dgamma, float* dbeta, int M, int C,
                        int accumulate_param_grads, float* dx_drop, float drop_p, uint64_t seed, uint64_t seed_off,
                        void* ws, size_t ws_bytes, void* stream);
+/* bf16-storage path (GEMM-facing tensors are bf16; statistics, the residual stream and all arithmetic stay fp32):
+ * layernorm_fwd_bf16out writes y as bf16; layernorm_bwd_bf16 reads dy as bf16 (dy16) or fp32, writes dx fp32 and dx_drop
+ * (nullable) = dropout(dx) as bf16 (drop_p = 0: a bf16 copy of dx, the next GEMM's operand). */
+int ds6g_layernorm_fwd_bf16out(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                               int M, int C, float eps, void* stream);
+int ds6g_layernorm_bwd_bf16(const void* dy, int dy16, const float* x, const float* mean, const float* rstd,
+                            const float* gamma, const float* add, float* dx, float* dgamma, float* dbeta, int M, int C,
+                            int accumulate_param_grads, void* dx_drop, float drop_p, uint64_t seed, uint64_t seed_off,
+                            void* ws, size_t ws_bytes, void* stream);
 /* bias gradients: out[c] (+)= sum_r x[r][c] */
 size_t ds6g_colsum_workspace_bytes(long M, int C);
 int ds6g_colsum(const float* x, long M, int C, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream);
@@ -164,6 +173,17 @@ int ds6g_attention_bwd(const float* q, const float* k, const float* v, const flo
                        const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int T, int nh, int hd,
                        int ld_qkv, int ld, int ld_dqkv, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
                        size_t ws_bytes, void* stream);
+
+/* bf16-storage path: q / k / v / d_o stay fp32 (column blocks of fp32 GEMM outputs); the forward output o is written -
+ * and read back by the backward - as bf16 [B*T][ld], dq / dk / dv are written as bf16 [B*T][ld_dqkv] (operands of the
+ * projection GEMMs).  The backward needs the full ds6g_attention_workspace_bytes (hand-over form). */
+int ds6g_attention_fwd_bf16out(const float* q, const float* k, const float* v, void* o, float* lse, int B, int T, int nh,
+                               int hd, int ld_qkv, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
+                               size_t ws_bytes, void* stream);
+int ds6g_attention_bwd_bf16(const float* q, const float* k, const float* v, const void* o, const float* d_o,
+                            const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int T, int nh, int hd,
+                            int ld_qkv, int ld, int ld_dqkv, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
+                            size_t ws_bytes, void* stream);
 
 /* ---- input.hip : device-side counterpart of CARLA_Data.__getitem__, data2_seq.py:42-173 --------
  * pack_image_u8: decoded RGB frame batch [B][H][W][3] uint8 (data2_seq.py:110-141, before its HWC->CHW transpose) ->
@@ -262,6 +282,8 @@ int ds6g_adamw_step(float* p, const float* g, float* m, float* v, float* shadow,
  * order: deterministic).  ws: >= 8 KiB + 8 bytes, its first 4 bytes zero on first use. */
 int ds6g_grad_norm_clip(const float* g, long n, float max_norm, float pre_scale, float* out, void* ws, size_t ws_bytes,
                         void* stream);
+/* dst (bf16, RNE) = src (fp32): refreshes the bf16 shadow of the parameter arena for the bf16-storage path */
+int ds6g_cast_f32_bf16(const float* src, void* dst, long n, void* stream);
 /* vel_emb1..4 and the join MLP: model2_seq.py:422-425,518,536,555,574,863-869 */
 int ds6g_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K,
                           int rows_per_group, long group_stride, int relu, void* stream);
