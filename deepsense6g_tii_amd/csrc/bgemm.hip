@@ -2,7 +2,7 @@
 // activations and a bf16 shadow of the weights live in HBM as bf16, accumulation is fp32, master weights / statistics /
 // loss / optimizer stay fp32).  Same three products as igemm.hip,
 //   FWD   : y[m][o]      = sum_{r,s,c} x[n, oh*st-p+r, ow*st-p+s, c] * w[o][r][s][c]
-//   DGRAD : dx[m][c]     = sum_{r,s,o} dy[n, h+p-r, w+p-s, o] * w[o][r][s][c]               (stride 1)
+//   DGRAD : dx[m][c]     = sum_{r,s,o} dy[n, (h+p-r)/st, (w+p-s)/st, o] * w[o][r][s][c]
 //   WGRAD : dw[o][r,s,c] = sum_{pixels} dy[pixel][o] * x[n, oh*st-p+r, ow*st-p+s, c]         (split-K, fp32 slabs)
 // on NHWC bf16 activations and OHWI bf16 weights; a Linear layer is the 1x1 case over ONE 1 x M "image".
 // Reference call sites: model2_seq.py:510-512,528-530,546-548,565-567 (BasicBlock convs), :83-90,:97-99,:109,:121-126
@@ -60,6 +60,11 @@ struct BgemmParams {
     int wg_rows;          // WGRAD: 0 = a k-tile of 64 pixels stays inside one output row; else output rows per k-tile
     int want_colsum;
     unsigned a_bytes, b_bytes;
+    // DGRAD of a strided conv runs per input-pixel parity class (blockIdx.y when nclass > 1, parameters derived in the
+    // kernel): pixels h = h0 + hstep*hh (hh < Hs), taps r = r0 + rstep*ri (ri < nr) - only the taps that hit a real
+    // output pixel, no structural zeros (as igemm.hip)
+    int nclass;
+    int h0, hstep, Hs, w0, wstep, Ws, r0, rstep, nr, s0, sstep, ns;
 };
 
 __device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(unsigned long)(lds_void*)p; }
@@ -67,7 +72,20 @@ __device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(u
 // MODE / BM x BN tile / OUT16: bf16 output through LDS (else fp32, direct) / EPI: fused epilogue (bias, ReLU, mask,
 // dropout, residual, accumulate) instead of a plain store
 template <int MODE, int BM, int BN, int OUT16, int EPI>
-__global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams p) {
+__global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
+    BgemmParams p = pin;
+    if (MODE == B_DGRAD && pin.nclass > 1) {
+        const int ph = blockIdx.y >> 1, pw = blockIdx.y & 1;
+        p.h0 = ph;
+        p.w0 = pw;
+        p.r0 = (ph + p.pad) & 1;
+        p.nr = p.r0 < p.R ? (p.R - p.r0 + 1) / 2 : 0;
+        p.s0 = (pw + p.pad) & 1;
+        p.ns = p.s0 < p.S ? (p.S - p.s0 + 1) / 2 : 0;
+        p.Kg = p.nr * p.ns * p.K;
+        if (p.ns == 0) p.ns = 1;
+        if (p.Kg == 0 && p.accumulate) return;  // no tap hits this class: its pixels keep their value
+    }
     constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 MFMA tiles per wave (wave grid 2 x 2)
     constexpr bool A_T = (MODE == B_WGRAD);            // operand staged [k][cols], read transposed
     constexpr bool B_T = (MODE != B_FWD);
@@ -127,8 +145,15 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams p) {
                 const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 a_vo[i] = ok ? (a_base[i] + (unsigned)((ih * p.W + iw) * p.C + a_c[i])) * 2u : OOB_OFF;
             } else if (MODE == B_DGRAD) {
-                const int oh = a_y[i] - u_r, ow = a_x[i] - u_s;
-                const bool ok = a_ok[i] && (unsigned)oh < (unsigned)p.Ho && (unsigned)ow < (unsigned)p.Wo;
+                const int th = a_y[i] - (p.r0 + u_r * p.rstep), tw = a_x[i] - (p.s0 + u_s * p.sstep);
+                int oh = th, ow = tw;
+                bool okk = th >= 0 && tw >= 0;
+                if (p.stride == 2) {
+                    oh = th >> 1;
+                    ow = tw >> 1;
+                    okk = okk && !((th | tw) & 1);
+                }
+                const bool ok = a_ok[i] && okk && oh < p.Ho && ow < p.Wo;
                 a_vo[i] = ok ? (a_base[i] + (unsigned)((oh * p.Wo + ow) * p.K + a_c[i])) * 2u : OOB_OFF;
             }
         }
@@ -148,9 +173,9 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams p) {
                 a_x[i] = ow * p.stride - p.pad;
                 a_base[i] = (unsigned)n * (unsigned)(p.H * p.W * p.C);
             } else {
-                const int w = mm % p.W, t = mm / p.W, h = t % p.H, n = t / p.H;
-                a_y[i] = h + p.pad;
-                a_x[i] = w + p.pad;
+                const int ww = mm % p.Ws, t = mm / p.Ws, hh = t % p.Hs, n = t / p.Hs;
+                a_y[i] = p.h0 + hh * p.hstep + p.pad;
+                a_x[i] = p.w0 + ww * p.wstep + p.pad;
                 a_base[i] = (unsigned)n * (unsigned)(p.Ho * p.Wo * p.K);
             }
         }
@@ -205,7 +230,8 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams p) {
         const unsigned la = lds_off(lds + st * STAGE), lb = la + A_BYTES;
         if (MODE == B_FWD || MODE == B_DGRAD) {
             const unsigned sa = (unsigned)u_c0 * 2u;
-            const unsigned sb = (MODE == B_FWD) ? u_kb : (unsigned)((u_c0 * (p.R * p.S) + u_r * p.S + u_s) * p.C) * 2u;
+            const unsigned sb = (MODE == B_FWD) ? u_kb
+                                                : (unsigned)((u_c0 * (p.R * p.S) + (p.r0 + u_r * p.rstep) * p.S + p.s0 + u_s * p.sstep) * p.C) * 2u;
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) dma16(a_rsrc, la + (unsigned)(i * 4 + wave) * 1024u, a_vo[i], sa);
 #pragma unroll
@@ -214,7 +240,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams p) {
             u_c0 += BK;
             if (u_c0 == ((MODE == B_FWD) ? p.C : p.K)) {
                 u_c0 = 0;
-                if (++u_s == p.S) { u_s = 0; ++u_r; }
+                if (++u_s == ((MODE == B_FWD) ? p.S : p.ns)) { u_s = 0; ++u_r; }
                 retap();
             }
         } else {
@@ -333,6 +359,30 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams p) {
     }
 
     // ---- epilogue: D[row][col], col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -------------------------
+    // strided dgrad: rows of the parity-class sub-grid scatter to full-resolution pixels
+    auto out_row = [&](int row) -> size_t {
+        if (!(MODE == B_DGRAD && p.hstep != 1)) return (size_t)row;
+        const int ww = row % p.Ws, t = row / p.Ws, hh = t % p.Hs;
+        return ((size_t)(t / p.Hs) * p.H + p.h0 + hh * p.hstep) * p.W + p.w0 + ww * p.wstep;
+    };
+    if (!OUT16 && MODE == B_DGRAD && p.hstep != 1) {
+        float* outp = reinterpret_cast<float*>(p.out);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+                if (col >= p.Ng) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    if (row >= p.Mg) continue;
+                    const size_t o = out_row(row) * p.Ng + col;
+                    outp[o] = p.accumulate ? outp[o] + acc[i][j][r] : acc[i][j][r];
+                }
+            }
+        return;
+    }
     if (!OUT16) {
         float* outp = reinterpret_cast<float*>(p.out) + ((MODE == B_WGRAD) ? (size_t)split * p.split_stride : (size_t)0);
         if (MODE == B_WGRAD && do_csum && m0 + tid < p.Mg) outp[(size_t)p.Mg * p.Ng + m0 + tid] = csum;
@@ -412,7 +462,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams p) {
             const int grow = m0 + wm * PR + rl, gcol = n0 + wn * PC + pc * 8;
             if (grow < p.Mg && gcol < p.Ng) {
                 bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + rl * PC + pc * 8);
-                bf16x8* dst = reinterpret_cast<bf16x8*>(outp + (size_t)grow * p.Ng + gcol);
+                bf16x8* dst = reinterpret_cast<bf16x8*>(outp + out_row(grow) * p.Ng + gcol);
                 if (p.accumulate) {
                     const bf16x8 old = *dst;
 #pragma unroll
@@ -433,6 +483,8 @@ void fill_conv(BgemmParams& p, int N, int H, int W, int C, int K, int R, int S, 
     p.Ho = (H + 2 * pad - R) / stride + 1;
     p.Wo = (W + 2 * pad - S) / stride + 1;
     p.drop_scale = 1.f;
+    p.h0 = 0; p.hstep = 1; p.Hs = H; p.w0 = 0; p.wstep = 1; p.Ws = W;
+    p.r0 = 0; p.rstep = 1; p.nr = R; p.s0 = 0; p.sstep = 1; p.ns = S;
 }
 
 // wgrad: the 64 pixels of a k-tile share one (image, output row), or cover whole output rows of one image
@@ -445,13 +497,14 @@ bool bgemm_wgrad_walk(BgemmParams& p) {
 template <int MODE, int OUT16, int EPI>
 int launch_tiles(BgemmParams& p, int splits, int tile, hipStream_t st) {
     dim3 block(256);
+    const int ny = p.nclass > 1 ? p.nclass : 1;
     if (tile == 0) {
         p.tiles_n = cdiv(p.Ng, 128);
-        dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, 1, splits);
+        dim3 grid(cdiv(p.Mg, 128) * p.tiles_n, ny, splits);
         hipLaunchKernelGGL((bgemm_kernel<MODE, 128, 128, OUT16, EPI>), grid, block, 0, st, p);
     } else {
         p.tiles_n = cdiv(p.Ng, 64);
-        dim3 grid(cdiv(p.Mg, 64) * p.tiles_n, 1, splits);
+        dim3 grid(cdiv(p.Mg, 64) * p.tiles_n, ny, splits);
         hipLaunchKernelGGL((bgemm_kernel<MODE, 64, 64, OUT16, EPI>), grid, block, 0, st, p);
     }
     DS6G_LAUNCH_CHECK();
@@ -528,17 +581,24 @@ int ds6g_bf16_conv2d_fwd(const void* x, const void* w, void* y, int out16, int N
     return launch_bgemm<B_FWD>(p, out16, 1, pick_tile(p.Mg, p.Ng, 1), (hipStream_t)stream);
 }
 
-// dx (+)= conv^T(dy, w), stride 1 only (the strided layers keep the fp32-storage kernel): dy bf16, w bf16, dx bf16 / fp32.
-// K % 64 == 0, C % 8 == 0.
+// dx (+)= conv^T(dy, w): dy bf16, w bf16, dx bf16 / fp32.  K % 64 == 0, C % 8 == 0; stride 1, or 2 with even H, W (the four
+// input-pixel parity classes of a stride-2 layer run as one launch).
 int ds6g_bf16_conv2d_dgrad(const void* dy, const void* w, void* dx, int out16, int N, int H, int W, int C, int K, int R,
                            int S, int stride, int pad, int accumulate, void* stream) {
     DS6G_ENTER();
-    DS6G_CHECK_ARG(dy && w && dx && K % BK == 0 && C % 8 == 0 && stride == 1);
+    DS6G_CHECK_ARG(dy && w && dx && K % BK == 0 && C % 8 == 0 && (stride == 1 || (stride == 2 && H % 2 == 0 && W % 2 == 0)));
     BgemmParams p;
     fill_conv(p, N, H, W, C, K, R, S, stride, pad);
     DS6G_CHECK_ARG(sizes_ok(p));
     p.a_src = (const __bf16*)dy; p.b_src = (const __bf16*)w; p.out = dx; p.accumulate = accumulate;
     p.a_bytes = (unsigned)((size_t)N * p.Ho * p.Wo * K * 2); p.b_bytes = (unsigned)((size_t)K * R * S * C * 2);
+    if (stride == 2) {
+        p.nclass = 4;
+        p.hstep = 2; p.Hs = H / 2; p.wstep = 2; p.Ws = W / 2; p.rstep = 2; p.sstep = 2;
+        p.nr = (R + 1) / 2; p.ns = (S + 1) / 2;
+        p.Mg = N * p.Hs * p.Ws; p.Ng = C; p.Kg = p.nr * p.ns * K;   // the largest class (tile choice); classes derive their own
+        return launch_bgemm<B_DGRAD>(p, out16, 1, pick_tile(p.Mg, p.Ng, 4), (hipStream_t)stream);
+    }
     p.Mg = N * H * W; p.Ng = C; p.Kg = R * S * K;
     return launch_bgemm<B_DGRAD>(p, out16, 1, pick_tile(p.Mg, p.Ng, 1), (hipStream_t)stream);
 }

@@ -52,9 +52,22 @@ __device__ __forceinline__ f32x4 bn_affine(const f32x4 x, const f32x4 mu, const 
     for (int j = 0; j < 4; ++j) r[j] = fmaf((x[j] - mu[j]) * is[j], g[j], b[j]);
     return r;
 }
+// four consecutive activation elements as fp32, whatever the storage type (fp32, or bf16 on the bf16-storage path:
+// the arithmetic of the normalisation / pooling / resampling kernels is fp32 either way)
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const __bf16* p) {
+    const bf16x4_t t = *reinterpret_cast<const bf16x4_t*>(p);
+    return f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+}
+__device__ __forceinline__ void st4(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(__bf16* p, const f32x4 v) {
+    *reinterpret_cast<bf16x4_t*>(p) = bf16x4_t{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+}
 // gradient of a 3x3 / stride 2 / pad 1 max-pool gathered on the fly: row = (n*H + h)*W + w of the pool INPUT; the up to
 // four windows covering that pixel contribute where their stored argmax (r*3 + s, one byte per channel) points at it
-struct PoolGrad { const float* dp; const uint8_t* idx; int H, W, Ho, Wo; };
+// (dp: fp32, or bf16 when dp16)
+struct PoolGrad { const void* dp; const uint8_t* idx; int H, W, Ho, Wo; int dp16; };
 __device__ __forceinline__ f32x4 pooled_grad(const PoolGrad& pg, long row, int c4, int C) {
     const int w = (int)(row % pg.W);
     const long t = row / pg.W;
@@ -69,7 +82,7 @@ __device__ __forceinline__ f32x4 pooled_grad(const PoolGrad& pg, long row, int c
             const int s = w - (ow * 2 - 1);
             const long o = ((n * pg.Ho + oh) * pg.Wo + ow) * C + c4;
             const uint32_t pk = *reinterpret_cast<const uint32_t*>(pg.idx + o);
-            const f32x4 g = *reinterpret_cast<const f32x4*>(pg.dp + o);
+            const f32x4 g = pg.dp16 ? ld4(reinterpret_cast<const __bf16*>(pg.dp) + o) : ld4(reinterpret_cast<const float*>(pg.dp) + o);
             const uint32_t me = (uint32_t)(r * 3 + s);
 #pragma unroll
             for (int j = 0; j < 4; ++j)

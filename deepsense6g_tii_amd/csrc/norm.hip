@@ -16,9 +16,9 @@ constexpr int FIN_GROUPS = 32;
 
 // partial[blk][0][c] = sum_rows a(r,c), partial[blk][1][c] = sum_rows b(r,c) in fp64.
 // MODE 0: a = x, b = x*x.   MODE 1: a = dyeff, b = dyeff * xhat  (BN backward)
-template <int MODE>
-__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                        const float* __restrict__ y_mask,
+template <int MODE, typename TX, typename TA>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const TX* __restrict__ x, const TA* __restrict__ dy,
+                                                        const TA* __restrict__ y_mask,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, long M, int C,
                                                         int rows_per_block, double* __restrict__ partial,
@@ -44,14 +44,14 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     }
     for (long r = r0 + rowlane; r < r1; r += rowlanes) {
         const size_t o = (size_t)r * C + colg * 4;
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
+        const f32x4 xv = ld4(x + o);
         if (MODE == 0) {
             s1 += xv;
             s2 += xv * xv;
         } else {
-            f32x4 g = pg.dp ? pooled_grad(pg, r, colg * 4, C) : *reinterpret_cast<const f32x4*>(dy + o);
+            f32x4 g = pg.dp ? pooled_grad(pg, r, colg * 4, C) : ld4(dy + o);
             if (y_mask || mg) {
-                const f32x4 yv = mg ? bn_affine(xv, mu, is, gam, bet) : *reinterpret_cast<const f32x4*>(y_mask + o);
+                const f32x4 yv = mg ? bn_affine(xv, mu, is, gam, bet) : ld4(y_mask + o);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
             }
@@ -117,11 +117,12 @@ __global__ void bn_eval_prepare_kernel(const float* __restrict__ running_mean, c
 }
 
 // y = relu?( (x - mean) * invstd * gamma + beta + residual? )
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+template <typename TA>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const TA* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
-                                                       const float* __restrict__ residual, float* __restrict__ y,
+                                                       const TA* __restrict__ residual, TA* __restrict__ y,
                                                        long total4, int C, int relu) {
     const int cg = C >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
@@ -130,14 +131,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4);
         const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c4);
         const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c4);
-        f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        f32x4 v = ld4(x + i * 4);
         v = bn_affine(v, mu, is, g, b);
-        if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
+        if (residual) v += ld4(residual + i * 4);
         if (relu) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
-        *reinterpret_cast<f32x4*>(y + i * 4) = v;
+        st4(y + i * 4, v);
     }
 }
 
@@ -176,13 +177,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     coef[2 * C + c] = (float)(s2 / (double)M);
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy,
-                                                           const float* __restrict__ y_mask,
-                                                           const float* __restrict__ x,
+template <typename TX, typename TA>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const TA* __restrict__ dy,
+                                                           const TA* __restrict__ y_mask,
+                                                           const TX* __restrict__ x,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
-                                                           const float* __restrict__ coef, float* __restrict__ dx,
-                                                           float* __restrict__ dres, long total4, int C,
+                                                           const float* __restrict__ coef, TX* __restrict__ dx,
+                                                           TA* __restrict__ dres, long total4, int C,
                                                            const float* __restrict__ mg, const float* __restrict__ mb,
                                                            const PoolGrad pg) {
     const int cg = C >> 2;
@@ -193,18 +195,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const f32x4 a = *reinterpret_cast<const f32x4*>(coef + c4);
         const f32x4 b = *reinterpret_cast<const f32x4*>(coef + C + c4);
         const f32x4 cc = *reinterpret_cast<const f32x4*>(coef + 2 * C + c4);
-        f32x4 g = pg.dp ? pooled_grad(pg, i / cg, c4, C) : *reinterpret_cast<const f32x4*>(dy + i * 4);
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
+        f32x4 g = pg.dp ? pooled_grad(pg, i / cg, c4, C) : ld4(dy + i * 4);
+        const f32x4 xv = ld4(x + i * 4);
         if (y_mask || mg) {
             const f32x4 yv = mg ? bn_affine(xv, mu, is, *reinterpret_cast<const f32x4*>(mg + c4),
                                             *reinterpret_cast<const f32x4*>(mb + c4))
-                                : *reinterpret_cast<const f32x4*>(y_mask + i * 4);
+                                : ld4(y_mask + i * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
         }
         const f32x4 xh = (xv - mu) * is;
-        if (dres) *reinterpret_cast<f32x4*>(dres + i * 4) = g;
-        *reinterpret_cast<f32x4*>(dx + i * 4) = a * (g - b - xh * cc);
+        if (dres) st4(dres + i * 4, g);
+        st4(dx + i * 4, a * (g - b - xh * cc));
     }
 }
 
@@ -438,6 +440,69 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ 
 }  // namespace
 
 extern "C" size_t ds6g_layernorm_bwd_workspace_bytes(int M, int C);
+extern "C" size_t ds6g_bn_workspace_bytes(long M, int C);
+
+// TX: storage type of the BN input x (and of dx); TA: of dy / y_mask / dres (the stem mixes fp32 x with a bf16 pool gradient)
+template <typename TX>
+static int bn_stats_run(const TX* x, long M, int C, float eps, float momentum, float* mean, float* invstd,
+                        float* running_mean, float* running_var, void* ws, size_t ws_bytes, void* stream) {
+    int rpb, nblk;
+    DS6G_CHECK_ARG(x && mean && invstd && ws && M > 0);
+    DS6G_CHECK_ARG(bn_geometry(M, C, &rpb, &nblk) == DS6G_OK);
+    DS6G_CHECK_ARG(ws_bytes >= ds6g_bn_workspace_bytes(M, C));
+    double* partial = (double*)ws;
+    const size_t lds = (size_t)(256 / (C / 4)) * 2 * C * sizeof(double);
+    hipLaunchKernelGGL((bn_reduce_kernel<0, TX, TX>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, x, (const TX*)nullptr,
+                       (const TX*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, rpb, partial,
+                       (const float*)nullptr, (const float*)nullptr, PoolGrad{});
+    DS6G_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk,
+                       M, C, eps, momentum, mean, invstd, running_mean, running_var);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+template <typename TA>
+static int bn_apply_run(const TA* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                        const TA* residual, TA* y, long M, int C, int relu, void* stream) {
+    DS6G_CHECK_ARG(x && mean && invstd && gamma && beta && y && C % 4 == 0);
+    const long total4 = M * C / 4;
+    const int grid = (int)min((long)8192, (total4 + 255) / 256);
+    hipLaunchKernelGGL((bn_apply_kernel<TA>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta,
+                       residual, y, total4, C, relu);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+// dyeff = dy * (y_mask > 0) (y_mask nullable); dx = gamma*invstd*(dyeff - mean(dyeff) - xhat*mean(dyeff*xhat));
+// dgamma/dbeta (+)=; dres (nullable) receives dyeff (gradient of the residual branch).
+// relu_beta (nullable, with y_mask NULL): the BN was followed by ReLU with NO residual added in between - the mask is
+// re-derived as (gamma * xhat + relu_beta > 0) from x, which the kernels read anyway, instead of reading the activation
+template <typename TX, typename TA>
+static int bn_bwd_run(const TA* dy, const PoolGrad pg, const TA* y_mask, const TX* x, const float* mean,
+                      const float* invstd, const float* gamma, const float* relu_beta, TX* dx, float* dgamma,
+                      float* dbeta, TA* dres, long M, int C, int accumulate_param_grads, void* ws, size_t ws_bytes,
+                      void* stream) {
+    const float* mg = relu_beta ? gamma : nullptr;
+    int rpb, nblk;
+    DS6G_CHECK_ARG(bn_geometry(M, C, &rpb, &nblk) == DS6G_OK);
+    DS6G_CHECK_ARG(ws_bytes >= ds6g_bn_workspace_bytes(M, C));
+    double* partial = (double*)ws;
+    float* coef = (float*)((char*)ws + (size_t)nblk * 2 * C * sizeof(double));
+    const size_t lds = (size_t)(256 / (C / 4)) * 2 * C * sizeof(double);
+    hipLaunchKernelGGL((bn_reduce_kernel<1, TX, TA>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, x, dy, y_mask, mean,
+                       invstd, M, C, rpb, partial, mg, relu_beta, pg);
+    DS6G_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk, M,
+                       C, gamma, invstd, dgamma, dbeta, coef, accumulate_param_grads);
+    DS6G_LAUNCH_CHECK();
+    const long total4 = M * C / 4;
+    const int grid = (int)min((long)8192, (total4 + 255) / 256);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<TX, TA>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, y_mask, x, mean,
+                       invstd, coef, dx, dres, total4, C, mg, relu_beta, pg);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
 
 template <typename TY>
 static int ln_fwd_launch(const float* x, const float* gamma, const float* beta, TY* y, float* mean, float* rstd, int M, int C,
@@ -494,19 +559,14 @@ size_t ds6g_bn_workspace_bytes(long M, int C) {
 int ds6g_bn_stats(const float* x, long M, int C, float eps, float momentum, float* mean, float* invstd,
                   float* running_mean, float* running_var, void* ws, size_t ws_bytes, void* stream) {
     DS6G_ENTER();
-    int rpb, nblk;
-    DS6G_CHECK_ARG(x && mean && invstd && ws && M > 0);
-    DS6G_CHECK_ARG(bn_geometry(M, C, &rpb, &nblk) == DS6G_OK);
-    DS6G_CHECK_ARG(ws_bytes >= ds6g_bn_workspace_bytes(M, C));
-    double* partial = (double*)ws;
-    const size_t lds = (size_t)(256 / (C / 4)) * 2 * C * sizeof(double);
-    hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, x, nullptr, nullptr,
-                       nullptr, nullptr, M, C, rpb, partial, nullptr, nullptr, PoolGrad{});
-    DS6G_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk,
-                       M, C, eps, momentum, mean, invstd, running_mean, running_var);
-    DS6G_LAUNCH_CHECK();
-    return DS6G_OK;
+    return bn_stats_run<float>(x, M, C, eps, momentum, mean, invstd, running_mean, running_var, ws, ws_bytes, stream);
+}
+// bf16-storage path: the conv output is bf16; statistics, running stats and all arithmetic stay fp32
+int ds6g_bf16_bn_stats(const void* x, long M, int C, float eps, float momentum, float* mean, float* invstd,
+                       float* running_mean, float* running_var, void* ws, size_t ws_bytes, void* stream) {
+    DS6G_ENTER();
+    return bn_stats_run<__bf16>((const __bf16*)x, M, C, eps, momentum, mean, invstd, running_mean, running_var, ws, ws_bytes,
+                                stream);
 }
 
 int ds6g_bn_eval_prepare(const float* running_mean, const float* running_var, int C, float eps, float* mean,
@@ -522,42 +582,13 @@ int ds6g_bn_eval_prepare(const float* running_mean, const float* running_var, in
 int ds6g_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                   const float* residual, float* y, long M, int C, int relu, void* stream) {
     DS6G_ENTER();
-    DS6G_CHECK_ARG(x && mean && invstd && gamma && beta && y && C % 4 == 0);
-    const long total4 = M * C / 4;
-    const int grid = (int)min((long)8192, (total4 + 255) / 256);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta,
-                       residual, y, total4, C, relu);
-    DS6G_LAUNCH_CHECK();
-    return DS6G_OK;
+    return bn_apply_run<float>(x, mean, invstd, gamma, beta, residual, y, M, C, relu, stream);
 }
-
-// dyeff = dy * (y_mask > 0) (y_mask nullable); dx = gamma*invstd*(dyeff - mean(dyeff) - xhat*mean(dyeff*xhat));
-// dgamma/dbeta (+)=; dres (nullable) receives dyeff (gradient of the residual branch).
-// relu_beta (nullable, with y_mask NULL): the BN was followed by ReLU with NO residual added in between - the mask is
-// re-derived as (gamma * xhat + relu_beta > 0) from x, which the kernels read anyway, instead of reading the activation
-static int bn_bwd_run(const float* dy, const PoolGrad pg, const float* y_mask, const float* x, const float* mean,
-                      const float* invstd, const float* gamma, const float* relu_beta, float* dx, float* dgamma,
-                      float* dbeta, float* dres, long M, int C, int accumulate_param_grads, void* ws, size_t ws_bytes,
-                      void* stream) {
-    const float* mg = relu_beta ? gamma : nullptr;
-    int rpb, nblk;
-    DS6G_CHECK_ARG(bn_geometry(M, C, &rpb, &nblk) == DS6G_OK);
-    DS6G_CHECK_ARG(ws_bytes >= ds6g_bn_workspace_bytes(M, C));
-    double* partial = (double*)ws;
-    float* coef = (float*)((char*)ws + (size_t)nblk * 2 * C * sizeof(double));
-    const size_t lds = (size_t)(256 / (C / 4)) * 2 * C * sizeof(double);
-    hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, x, dy, y_mask, mean,
-                       invstd, M, C, rpb, partial, mg, relu_beta, pg);
-    DS6G_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk, M,
-                       C, gamma, invstd, dgamma, dbeta, coef, accumulate_param_grads);
-    DS6G_LAUNCH_CHECK();
-    const long total4 = M * C / 4;
-    const int grid = (int)min((long)8192, (total4 + 255) / 256);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, y_mask, x, mean,
-                       invstd, coef, dx, dres, total4, C, mg, relu_beta, pg);
-    DS6G_LAUNCH_CHECK();
-    return DS6G_OK;
+int ds6g_bf16_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                       const void* residual, void* y, long M, int C, int relu, void* stream) {
+    DS6G_ENTER();
+    return bn_apply_run<__bf16>((const __bf16*)x, mean, invstd, gamma, beta, (const __bf16*)residual, (__bf16*)y, M, C, relu,
+                                stream);
 }
 
 int ds6g_bn_bwd(const float* dy, const float* y_mask, const float* x, const float* mean, const float* invstd,
@@ -566,22 +597,50 @@ int ds6g_bn_bwd(const float* dy, const float* y_mask, const float* x, const floa
     DS6G_ENTER();
     DS6G_CHECK_ARG(!(y_mask && relu_beta));
     DS6G_CHECK_ARG(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && ws);
-    return bn_bwd_run(dy, PoolGrad{}, y_mask, x, mean, invstd, gamma, relu_beta, dx, dgamma, dbeta, dres, M, C,
-                      accumulate_param_grads, ws, ws_bytes, stream);
+    return bn_bwd_run<float, float>(dy, PoolGrad{}, y_mask, x, mean, invstd, gamma, relu_beta, dx, dgamma, dbeta, dres, M, C,
+                                    accumulate_param_grads, ws, ws_bytes, stream);
+}
+// bf16-storage path: dy / y_mask / x / dx / dres bf16 (dgamma / dbeta and the reductions fp32 / fp64)
+int ds6g_bf16_bn_bwd(const void* dy, const void* y_mask, const void* x, const float* mean, const float* invstd,
+                     const float* gamma, const float* relu_beta, void* dx, float* dgamma, float* dbeta, void* dres, long M,
+                     int C, int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(!(y_mask && relu_beta));
+    DS6G_CHECK_ARG(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && ws);
+    return bn_bwd_run<__bf16, __bf16>((const __bf16*)dy, PoolGrad{}, (const __bf16*)y_mask, (const __bf16*)x, mean, invstd,
+                                      gamma, relu_beta, (__bf16*)dx, dgamma, dbeta, (__bf16*)dres, M, C,
+                                      accumulate_param_grads, ws, ws_bytes, stream);
 }
 
 // BN -> ReLU -> 3x3/2 max-pool (the ResNet stem, model2_seq.py:495-500 via torchvision) backward in one pass over x: the
 // pool gradient is gathered from (dpool, idx) where the BN kernels would read dy, so the dense [N][H][W][C] gradient of
 // the pool input is never written or read
+static int bn_bwd_maxpool_impl(const void* dpool, int dp16, const uint8_t* idx, const float* x, const float* mean,
+                               const float* invstd, const float* gamma, const float* relu_beta, float* dx, float* dgamma,
+                               float* dbeta, int N, int H, int W, int C, int accumulate_param_grads, void* ws,
+                               size_t ws_bytes, void* stream) {
+    DS6G_CHECK_ARG(dpool && idx && x && mean && invstd && gamma && relu_beta && dx && dgamma && dbeta && ws);
+    DS6G_CHECK_ARG(N > 0 && H > 0 && W > 0 && C % 4 == 0);
+    const PoolGrad pg{dpool, idx, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, dp16};
+    return bn_bwd_run<float, float>(nullptr, pg, nullptr, x, mean, invstd, gamma, relu_beta, dx, dgamma, dbeta, nullptr,
+                                    (long)N * H * W, C, accumulate_param_grads, ws, ws_bytes, stream);
+}
 int ds6g_bn_bwd_maxpool(const float* dpool, const uint8_t* idx, const float* x, const float* mean, const float* invstd,
                         const float* gamma, const float* relu_beta, float* dx, float* dgamma, float* dbeta, int N, int H,
                         int W, int C, int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream) {
     DS6G_ENTER();
-    DS6G_CHECK_ARG(dpool && idx && x && mean && invstd && gamma && relu_beta && dx && dgamma && dbeta && ws);
-    DS6G_CHECK_ARG(N > 0 && H > 0 && W > 0 && C % 4 == 0);
-    const PoolGrad pg{dpool, idx, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1};
-    return bn_bwd_run(nullptr, pg, nullptr, x, mean, invstd, gamma, relu_beta, dx, dgamma, dbeta, nullptr,
-                      (long)N * H * W, C, accumulate_param_grads, ws, ws_bytes, stream);
+    return bn_bwd_maxpool_impl(dpool, 0, idx, x, mean, invstd, gamma, relu_beta, dx, dgamma, dbeta, N, H, W, C,
+                               accumulate_param_grads, ws, ws_bytes, stream);
+}
+// bf16-storage path: the stem's conv output x and its gradient dx stay fp32 (the 4-channel stem keeps the fp32-storage
+// kernels), the gradient of the pooled tensor arrives as bf16
+int ds6g_bn_bwd_maxpool_bf16in(const void* dpool, const uint8_t* idx, const float* x, const float* mean,
+                               const float* invstd, const float* gamma, const float* relu_beta, float* dx, float* dgamma,
+                               float* dbeta, int N, int H, int W, int C, int accumulate_param_grads, void* ws,
+                               size_t ws_bytes, void* stream) {
+    DS6G_ENTER();
+    return bn_bwd_maxpool_impl(dpool, 1, idx, x, mean, invstd, gamma, relu_beta, dx, dgamma, dbeta, N, H, W, C,
+                               accumulate_param_grads, ws, ws_bytes, stream);
 }
 
 int ds6g_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

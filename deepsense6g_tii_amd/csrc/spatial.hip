@@ -61,7 +61,8 @@ __global__ void pad_channels_kernel(const float* __restrict__ src, float* __rest
 
 // ------------------------------------------------------------------------------------------------
 // bn_mean != NULL: the pooled tensor is relu(BN(x)), evaluated on the fly (the activation is never materialised)
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <typename TY>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, TY* __restrict__ y,
                                                           uint8_t* __restrict__ idx, int N, int H, int W, int C,
                                                           int Ho, int Wo, const float* __restrict__ bn_mean,
                                                           const float* __restrict__ bn_invstd,
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
         }
     }
     const long o = (((long)n * Ho + oh) * Wo + ow) * C + c4;
-    *reinterpret_cast<f32x4*>(y + o) = best;
+    st4(y + o, best);
     *reinterpret_cast<uint32_t*>(idx + o) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
 }
 
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------------
 // tokens[row(f,ph,pw)][c] = dropout( mean_{k x k window} feat + pos_emb[tok][c] )
-__global__ __launch_bounds__(256) void avgpool_tokens_fwd_kernel(const float* __restrict__ feat,
+template <typename TF>
+__global__ __launch_bounds__(256) void avgpool_tokens_fwd_kernel(const TF* __restrict__ feat,
                                                                  const float* __restrict__ pos_emb,
                                                                  float* __restrict__ tokens, int N, int H, int C,
                                                                  int fps, int mod_off, int T, uint32_t thr,
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void avgpool_tokens_fwd_kernel(const float* __
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int r = 0; r < k; ++r)
         for (int q = 0; q < k; ++q)
-            s += *reinterpret_cast<const f32x4*>(feat + (((long)f * H + ph * k + r) * H + pw * k + q) * C + c4);
+            s += ld4(feat + (((long)f * H + ph * k + r) * H + pw * k + q) * C + c4);
     s *= 1.0f / (float)(k * k);
     const long row = tok_row(f, fps, mod_off, T, hw);
     const int tok = (int)(row % T);
@@ -196,9 +198,10 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 }
 
 // dfeat[f,h,w,c] = dfeat_in[f,h,w,c] + dtok[row(f,h/k,w/k)][c] / k^2
+template <typename TF>
 __global__ __launch_bounds__(256) void avgpool_tokens_bwd_kernel(const float* __restrict__ dtok,
-                                                                 const float* __restrict__ dfeat_in,
-                                                                 float* __restrict__ dfeat, int N, int H, int C,
+                                                                 const TF* __restrict__ dfeat_in,
+                                                                 TF* __restrict__ dfeat, int N, int H, int C,
                                                                  int fps, int mod_off, int T) {
     const int cg = C >> 2;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -211,8 +214,8 @@ __global__ __launch_bounds__(256) void avgpool_tokens_bwd_kernel(const float* __
     const int k = H >> 3;
     const long row = tok_row(f, fps, mod_off, T, (h / k) * 8 + (w / k));
     f32x4 g = *reinterpret_cast<const f32x4*>(dtok + row * C + c4) * (1.0f / (float)(k * k));
-    if (dfeat_in) g += *reinterpret_cast<const f32x4*>(dfeat_in + i * 4);
-    *reinterpret_cast<f32x4*>(dfeat + i * 4) = g;
+    if (dfeat_in) g += ld4(dfeat_in + i * 4);
+    st4(dfeat + i * 4, g);
 }
 
 // PyTorch bilinear, align_corners=False, scale_factor given: src = max((dst+0.5)/scale - 0.5, 0)
@@ -225,9 +228,10 @@ __device__ __forceinline__ void bilin_src(int d, float inv_scale, int in_size, i
 }
 
 // out[f,h,w,c] = feat[f,h,w,c] + bilinear_up(tokmap[f])[h,w,c]; tokmap rows live in the token buffer
-__global__ __launch_bounds__(256) void upsample_add_fwd_kernel(const float* __restrict__ feat,
+template <typename TF>
+__global__ __launch_bounds__(256) void upsample_add_fwd_kernel(const TF* __restrict__ feat,
                                                                const float* __restrict__ tokens,
-                                                               float* __restrict__ out, int N, int H, int C, int fps,
+                                                               TF* __restrict__ out, int N, int H, int C, int fps,
                                                                int mod_off, int T) {
     const int cg = C >> 2;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,14 +252,15 @@ __global__ __launch_bounds__(256) void upsample_add_fwd_kernel(const float* __re
     const f32x4 v10 = *reinterpret_cast<const f32x4*>(tokens + (base + h1 * 8 + w0) * C + c4);
     const f32x4 v11 = *reinterpret_cast<const f32x4*>(tokens + (base + h1 * 8 + w1) * C + c4);
     const f32x4 up = (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
-    *reinterpret_cast<f32x4*>(out + i * 4) = *reinterpret_cast<const f32x4*>(feat + i * 4) + up;
+    st4(out + i * 4, ld4(feat + i * 4) + up);
 }
 
 // dtok[row(f,ph,pw)][c] = sum_{h,w} wh(h,ph) ww(w,pw) dout[f,h,w,c]   (adjoint of the upsample).
 // One workgroup per token cell (f, ph, pw): the <= 4k x 4k window of contributing pixels (k = H/8) is split over
 // 256 / (C/4) row slices, the 1-D bilinear weights are tabulated once per workgroup, partial sums meet in LDS.
 constexpr int UPB_MAXWIN = 64;  // window rows / columns per cell (4 * H/8, H <= 128)
-__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const float* __restrict__ dout,
+template <typename TF>
+__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const TF* __restrict__ dout,
                                                                float* __restrict__ dtok, int N, int H, int C, int fps,
                                                                int mod_off, int T) {
     __shared__ float whs[UPB_MAXWIN], wws[UPB_MAXWIN];
@@ -294,10 +299,10 @@ __global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const float* __re
             for (int h = hlo + sl; h < hhi; h += slices) {
                 const float wh = whs[h - hlo];
                 if (wh == 0.f) continue;
-                const float* row = dout + (((long)f * H + h) * H) * C + c4;
+                const TF* row = dout + (((long)f * H + h) * H) * C + c4;
                 for (int w = wlo; w < whi; ++w) {
                     const float ww = wws[w - wlo];
-                    if (ww != 0.f) acc += (wh * ww) * *reinterpret_cast<const f32x4*>(row + (long)w * C);
+                    if (ww != 0.f) acc += (wh * ww) * ld4(row + (long)w * C);
                 }
             }
         }
@@ -313,7 +318,8 @@ __global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const float* __re
 
 // ------------------------------------------------------------------------------------------------
 // pooled[f][c] = mean over the 64 pixels of the 8x8 map (features.avgpool + flatten)
-__global__ __launch_bounds__(256) void global_pool_kernel(const float* __restrict__ feat, float* __restrict__ pooled,
+template <typename TF>
+__global__ __launch_bounds__(256) void global_pool_kernel(const TF* __restrict__ feat, float* __restrict__ pooled,
                                                           int N, int C) {
     const int cg = C >> 2;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(256) void global_pool_kernel(const float* __restric
     const int c4 = (int)(i % cg) * 4;
     const int f = (int)(i / cg);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int p = 0; p < 64; ++p) s += *reinterpret_cast<const f32x4*>(feat + ((long)f * 64 + p) * C + c4);
+    for (int p = 0; p < 64; ++p) s += ld4(feat + ((long)f * 64 + p) * C + c4);
     *reinterpret_cast<f32x4*>(pooled + (long)f * C + c4) = s * (1.0f / 64.0f);
 }
 
@@ -345,7 +351,8 @@ __global__ void head_sum_kernel(const float* __restrict__ p0, const float* __res
 
 // backward of head: dfeat[f][p][c] = dfused[b][c]/64 for every frame; dtok rows: same value for
 // the spatial rows (scale-1 residual add) and dfused[b][c] for the two GPS rows
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dfused, float* __restrict__ dfeat,
+template <typename TF>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dfused, TF* __restrict__ dfeat,
                                                        int N, int C, int fps) {
     const int cg = C >> 2;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     const int c4 = (int)(i % cg) * 4;
     const int f = (int)(i / ((long)64 * cg));
     const int b = f / fps;
-    *reinterpret_cast<f32x4*>(dfeat + i * 4) = *reinterpret_cast<const f32x4*>(dfused + (long)b * C + c4) * (1.0f / 64.0f);
+    st4(dfeat + i * 4, *reinterpret_cast<const f32x4*>(dfused + (long)b * C + c4) * (1.0f / 64.0f));
 }
 
 // dtok[row(f,hw)][c] = dfeat[f][hw][c] (scale-1 stage: feature and token gradients coincide)
@@ -439,7 +446,7 @@ int ds6g_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, 
     DS6G_ENTER();
     DS6G_CHECK_ARG(x && y && idx && C % 4 == 0);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid1((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
+    hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(grid1((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
                        (hipStream_t)stream, x, y, idx, N, H, W, C, Ho, Wo, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr);
     DS6G_LAUNCH_CHECK();
@@ -453,7 +460,7 @@ int ds6g_bn_relu_maxpool3x3s2_fwd(const float* x, const float* mean, const float
     DS6G_ENTER();
     DS6G_CHECK_ARG(x && mean && invstd && gamma && beta && y && idx && C % 4 == 0 && N > 0 && H > 0 && W > 0);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid1((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
+    hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(grid1((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
                        (hipStream_t)stream, x, y, idx, N, H, W, C, Ho, Wo, mean, invstd, gamma, beta);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
@@ -474,7 +481,7 @@ int ds6g_avgpool_tokens_fwd(const float* feat, const float* pos_emb, float* toke
                             uint64_t seed_off, void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(feat && pos_emb && tokens && C % 4 == 0 && H % 8 == 0 && N % frames_per_sample == 0);
-    hipLaunchKernelGGL(avgpool_tokens_fwd_kernel, dim3(grid1((long)N * 64 * (C / 4))), dim3(256), 0,
+    hipLaunchKernelGGL((avgpool_tokens_fwd_kernel<float>), dim3(grid1((long)N * 64 * (C / 4))), dim3(256), 0,
                        (hipStream_t)stream, feat, pos_emb, tokens, N, H, C, frames_per_sample, mod_off, T,
                        ds6g_drop_threshold(drop_p), 1.f / (1.f - drop_p), seed, seed_off);
     DS6G_LAUNCH_CHECK();
@@ -505,7 +512,7 @@ int ds6g_avgpool_tokens_bwd(const float* dtok, const float* dfeat_in, float* dfe
                             int frames_per_sample, int mod_off, int T, void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(dtok && dfeat && C % 4 == 0 && H % 8 == 0);
-    hipLaunchKernelGGL(avgpool_tokens_bwd_kernel, dim3(grid1((long)N * H * H * (C / 4))), dim3(256), 0,
+    hipLaunchKernelGGL((avgpool_tokens_bwd_kernel<float>), dim3(grid1((long)N * H * H * (C / 4))), dim3(256), 0,
                        (hipStream_t)stream, dtok, dfeat_in, dfeat, N, H, C, frames_per_sample, mod_off, T);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
@@ -515,7 +522,7 @@ int ds6g_upsample_add_fwd(const float* feat, const float* tokens, float* out, in
                           int frames_per_sample, int mod_off, int T, void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(feat && tokens && out && C % 4 == 0 && H % 8 == 0);
-    hipLaunchKernelGGL(upsample_add_fwd_kernel, dim3(grid1((long)N * H * H * (C / 4))), dim3(256), 0,
+    hipLaunchKernelGGL((upsample_add_fwd_kernel<float>), dim3(grid1((long)N * H * H * (C / 4))), dim3(256), 0,
                        (hipStream_t)stream, feat, tokens, out, N, H, C, frames_per_sample, mod_off, T);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
@@ -525,7 +532,7 @@ int ds6g_upsample_add_bwd(const float* dout, float* dtok, int N, int H, int C, i
                           int T, void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(dout && dtok && C % 4 == 0 && H % 8 == 0 && 5 * (H / 8) <= UPB_MAXWIN && N > 0);
-    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(N * 64), dim3(256), 0, (hipStream_t)stream, dout, dtok, N, H, C,
+    hipLaunchKernelGGL((upsample_add_bwd_kernel<float>), dim3(N * 64), dim3(256), 0, (hipStream_t)stream, dout, dtok, N, H, C,
                        frames_per_sample, mod_off, T);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
@@ -534,7 +541,7 @@ int ds6g_upsample_add_bwd(const float* dout, float* dtok, int N, int H, int C, i
 int ds6g_global_pool(const float* feat, float* pooled, int N, int C, void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(feat && pooled && C % 4 == 0);
-    hipLaunchKernelGGL(global_pool_kernel, dim3(grid1((long)N * (C / 4))), dim3(256), 0, (hipStream_t)stream, feat,
+    hipLaunchKernelGGL((global_pool_kernel<float>), dim3(grid1((long)N * (C / 4))), dim3(256), 0, (hipStream_t)stream, feat,
                        pooled, N, C);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
@@ -553,7 +560,7 @@ int ds6g_head_sum(const float* pooled_img, const float* pooled_lidar, const floa
 int ds6g_head_bwd(const float* dfused, float* dfeat, int N, int C, int frames_per_sample, void* stream) {
     DS6G_ENTER();
     DS6G_CHECK_ARG(dfused && dfeat && C % 4 == 0);
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(grid1((long)N * 64 * (C / 4))), dim3(256), 0, (hipStream_t)stream, dfused,
+    hipLaunchKernelGGL((head_bwd_kernel<float>), dim3(grid1((long)N * 64 * (C / 4))), dim3(256), 0, (hipStream_t)stream, dfused,
                        dfeat, N, C, frames_per_sample);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
@@ -597,6 +604,79 @@ int ds6g_batch_sum(const float* src, float* out, long n, int count, long stride,
     DS6G_CHECK_ARG(src && out && n % 4 == 0 && stride % 4 == 0);
     hipLaunchKernelGGL(batch_sum_kernel, dim3(grid1(n / 4)), dim3(256), 0, (hipStream_t)stream, src, out, n / 4, count,
                        (size_t)stride, accumulate);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+// ---- bf16-storage path: the same kernels on bf16 feature maps (tokens, pos_emb, pooled vectors and all arithmetic fp32) ----
+int ds6g_bn_relu_maxpool3x3s2_fwd_bf16out(const float* x, const float* mean, const float* invstd, const float* gamma,
+                                          const float* beta, void* y, uint8_t* idx, int N, int H, int W, int C,
+                                          void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && mean && invstd && gamma && beta && y && idx && C % 4 == 0 && N > 0 && H > 0 && W > 0);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL((maxpool_fwd_kernel<__bf16>), dim3(grid1((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, x, (__bf16*)y, idx, N, H, W, C, Ho, Wo, mean, invstd, gamma, beta);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+int ds6g_bf16_avgpool_tokens_fwd(const void* feat, const float* pos_emb, float* tokens, int N, int H, int C,
+                                 int frames_per_sample, int mod_off, int T, float drop_p, uint64_t seed,
+                                 uint64_t seed_off, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(feat && pos_emb && tokens && C % 4 == 0 && H % 8 == 0 && N % frames_per_sample == 0);
+    hipLaunchKernelGGL((avgpool_tokens_fwd_kernel<__bf16>), dim3(grid1((long)N * 64 * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, (const __bf16*)feat, pos_emb, tokens, N, H, C, frames_per_sample, mod_off, T,
+                       ds6g_drop_threshold(drop_p), 1.f / (1.f - drop_p), seed, seed_off);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+int ds6g_bf16_avgpool_tokens_bwd(const float* dtok, const void* dfeat_in, void* dfeat, int N, int H, int C,
+                                 int frames_per_sample, int mod_off, int T, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(dtok && dfeat && C % 4 == 0 && H % 8 == 0);
+    hipLaunchKernelGGL((avgpool_tokens_bwd_kernel<__bf16>), dim3(grid1((long)N * H * H * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, dtok, (const __bf16*)dfeat_in, (__bf16*)dfeat, N, H, C, frames_per_sample, mod_off, T);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+int ds6g_bf16_upsample_add_fwd(const void* feat, const float* tokens, void* out, int N, int H, int C,
+                               int frames_per_sample, int mod_off, int T, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(feat && tokens && out && C % 4 == 0 && H % 8 == 0);
+    hipLaunchKernelGGL((upsample_add_fwd_kernel<__bf16>), dim3(grid1((long)N * H * H * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, (const __bf16*)feat, tokens, (__bf16*)out, N, H, C, frames_per_sample, mod_off, T);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+int ds6g_bf16_upsample_add_bwd(const void* dout, float* dtok, int N, int H, int C, int frames_per_sample, int mod_off,
+                               int T, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(dout && dtok && C % 4 == 0 && H % 8 == 0 && 5 * (H / 8) <= UPB_MAXWIN && N > 0);
+    hipLaunchKernelGGL((upsample_add_bwd_kernel<__bf16>), dim3(N * 64), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)dout, dtok, N, H, C, frames_per_sample, mod_off, T);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+int ds6g_bf16_global_pool(const void* feat, float* pooled, int N, int C, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(feat && pooled && C % 4 == 0);
+    hipLaunchKernelGGL((global_pool_kernel<__bf16>), dim3(grid1((long)N * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)feat, pooled, N, C);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+int ds6g_bf16_head_bwd(const float* dfused, void* dfeat, int N, int C, int frames_per_sample, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(dfused && dfeat && C % 4 == 0);
+    hipLaunchKernelGGL((head_bwd_kernel<__bf16>), dim3(grid1((long)N * 64 * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       dfused, (__bf16*)dfeat, N, C, frames_per_sample);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }

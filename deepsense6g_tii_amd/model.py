@@ -611,7 +611,8 @@ class TransFuser(nn.Module):
             else:
                 ops.bn_eval_prepare(bn.running_mean.data_ptr(), bn.running_var.data_ptr(), 64, stats[0], stats[1], bn.eps)
             st1 = (stats[0], stats[1])
-            p1, idx = ops.bn_relu_maxpool(c1, st1[0], st1[1], self._w(bn.weight), self._w(bn.bias))
+            pool = ops.bn_relu_maxpool_bf16out if self._use16 else ops.bn_relu_maxpool
+            p1, idx = pool(c1, st1[0], st1[1], self._w(bn.weight), self._w(bn.bias))
             return p1, (x, c1, None, st1, idx, cin)
         N, H1, W1, _ = a1.shape
         Ho, Wo = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
@@ -641,7 +642,67 @@ class TransFuser(nn.Module):
             return ops.conv3x3_winograd(dy, ud, x_shape[-1], out=out, accumulate=accumulate)
         return ops.conv2d_dgrad(dy, self._w(conv.weight), tuple(x_shape), 3, 3, stride, 1, out=out, accumulate=accumulate)
 
+    def _bn_fwd16(self, bn, x, relu, residual, train):
+        C = x.shape[-1]
+        stats = torch.empty(2, C, dtype=F32, device=x.device)
+        if train:
+            ops.bf16_bn_stats(x.numel() // C, C, x, stats[0], stats[1], bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                              self._ws, bn.eps, bn.momentum)
+        else:
+            ops.bn_eval_prepare(bn.running_mean.data_ptr(), bn.running_var.data_ptr(), C, stats[0], stats[1], bn.eps)
+        y = ops.bf16_bn_apply(x, stats[0], stats[1], self._w(bn.weight), self._w(bn.bias), relu, residual)
+        return y, (stats[0], stats[1])
+
+    def _block_fwd16(self, blk, x, train):
+        """BasicBlock on bf16-stored feature maps: convs on csrc/bgemm.hip (direct implicit GEMM, bf16 tiles, bf16 weight
+        shadow), BatchNorm reading / writing bf16 with fp32 statistics.  Same tape layout as _block_fwd."""
+        K = blk.conv1.out_channels
+        c1 = ops.bf16_conv2d_fwd(x, self._w16(blk.conv1.weight), K, 3, 3, blk.stride, 1)
+        a1, s1 = self._bn_fwd16(blk.bn1, c1, True, None, train)
+        c2 = ops.bf16_conv2d_fwd(a1, self._w16(blk.conv2.weight), K, 3, 3, 1, 1)
+        if blk.downsample is not None:
+            cd = ops.bf16_conv2d_fwd(x, self._w16(blk.downsample[0].weight), K, 1, 1, blk.stride, 0)
+            idn, sd = self._bn_fwd16(blk.downsample[1], cd, False, None, train)
+        else:
+            cd, sd, idn = None, None, x
+        out, s2 = self._bn_fwd16(blk.bn2, c2, True, idn, train)
+        return out, (x, c1, a1, s1, c2, s2, cd, sd, out, None, None)
+
+    def _block_bwd16(self, blk, ctx, dout):
+        x, c1, a1, s1, c2, s2, cd, sd, out, _, _ = ctx
+
+        def bn_bwd(bn, dy, y_mask, xin, stats, want_dres=False, relu_no_residual=False):
+            gw, aw = self._g(bn.weight)
+            gb, _ = self._g(bn.bias)
+            return ops.bf16_bn_bwd(dy, None if relu_no_residual else y_mask, xin, stats[0], stats[1], self._w(bn.weight), gw,
+                                   gb, self._ws, want_dres=want_dres, accumulate=bool(aw),
+                                   relu_beta_ptr=self._w(bn.bias) if relu_no_residual else 0)
+
+        def wgrad(conv, xin, dy, R, stride, pad):
+            gp, acc = self._g(conv.weight)
+            self._wg_launch(lambda: ops.bf16_conv2d_wgrad(xin, dy, gp, R, R, stride, pad, self._ws, accumulate=bool(acc)),
+                            (xin, dy))
+
+        dc2, dres = bn_bwd(blk.bn2, dout, out, c2, s2, want_dres=True)
+        wgrad(blk.conv2, a1, dc2, 3, 1, 1)
+        da1 = ops.bf16_conv2d_dgrad(dc2, self._w16(blk.conv2.weight), tuple(a1.shape), 3, 3, 1, 1)
+        dc1, _ = bn_bwd(blk.bn1, da1, a1, c1, s1, relu_no_residual=True)
+        wgrad(blk.conv1, x, dc1, 3, blk.stride, 1)
+        if blk.downsample is not None:
+            dcd, _ = bn_bwd(blk.downsample[1], dres, None, cd, sd)
+            wgrad(blk.downsample[0], x, dcd, 1, blk.stride, 0)
+            dx = ops.bf16_conv2d_dgrad(dc1, self._w16(blk.conv1.weight), tuple(x.shape), 3, 3, blk.stride, 1)
+            ops.bf16_conv2d_dgrad(dcd, self._w16(blk.downsample[0].weight), tuple(x.shape), 1, 1, blk.stride, 0, out=dx,
+                                  accumulate=True)
+        else:
+            dx = dres
+            ops.bf16_conv2d_dgrad(dc1, self._w16(blk.conv1.weight), tuple(x.shape), 3, 3, blk.stride, 1, out=dx,
+                                  accumulate=True)
+        return dx
+
     def _block_fwd(self, blk, x, train):
+        if x.dtype == torch.bfloat16:
+            return self._block_fwd16(blk, x, train)
         K = blk.conv1.out_channels
         if self._fold_now:
             # inference: eval-mode BN is an affine map per channel - folded into the conv weights, the block is three
@@ -793,11 +854,12 @@ class TransFuser(nn.Module):
         x0 = torch.empty((B, T, C), dtype=F32, device=self.device)
         off_e = self._next_drop(x0.numel()) if pe > 0 else 0
         pos = self._w(gpt.pos_emb)
+        f16 = feats[0].dtype == torch.bfloat16   # bf16-storage path: feature maps bf16, tokens fp32
         for m in range(3):
             N, H = feats[m].shape[0], feats[m].shape[1]
-            assert feats[m].shape == (B * fps[m], H, H, C)
-            L.avgpool_tokens_fwd(feats[m].data_ptr(), pos, x0.data_ptr(), N, H, C, fps[m], offs[m], T, pe,
-                                 self._seed, off_e, st)
+            assert feats[m].shape == (B * fps[m], H, H, C) and (feats[m].dtype == torch.bfloat16) == f16
+            (L.bf16_avgpool_tokens_fwd if f16 else L.avgpool_tokens_fwd)(
+                feats[m].data_ptr(), pos, x0.data_ptr(), N, H, C, fps[m], offs[m], T, pe, self._seed, off_e, st)
         _, gptr, rpg, gstride, K = gps_src
         gemb = torch.empty((B, 2, C), dtype=F32, device=self.device)
         L.small_linear_fwd(gptr, self._w(vel.weight), self._w(vel.bias), gemb.data_ptr(), 2 * B, C, K, rpg, gstride,
@@ -813,7 +875,8 @@ class TransFuser(nn.Module):
         for m in range(3):
             N, H = feats[m].shape[0], feats[m].shape[1]
             o = torch.empty_like(feats[m])
-            L.upsample_add_fwd(feats[m].data_ptr(), xo.data_ptr(), o.data_ptr(), N, H, C, fps[m], offs[m], T, st)
+            (L.bf16_upsample_add_fwd if f16 else L.upsample_add_fwd)(
+                feats[m].data_ptr(), xo.data_ptr(), o.data_ptr(), N, H, C, fps[m], offs[m], T, st)
             outs.append(o)
         ctx = (s, C, T, fps, offs, pe, off_e, gps_src, blk_ctx, x, mf, rf, [f.shape for f in feats])
         return outs, xo, ctx
@@ -826,6 +889,8 @@ class TransFuser(nn.Module):
         self._fold_now = self.fold_bn_eval and not train and not record  # inference only: backward needs the BN tape
         self._recording = bool(record)
         self._refresh_shadow16()
+        if self._fold_now:
+            self._use16 = False   # folded inference convs read the fp32 weights (BN folded per call)
         S = cfg.seq_len
         if torch.is_tensor(lidars):
             B = lidars.shape[0] // S
@@ -884,7 +949,7 @@ class TransFuser(nn.Module):
             N = feats[m].shape[0]
             assert feats[m].shape[1:] == (8, 8, 512)
             pl = torch.empty((N, 512), dtype=F32, device=self.device)
-            L.global_pool(feats[m].data_ptr(), pl.data_ptr(), N, 512, st)
+            (L.bf16_global_pool if feats[m].dtype == torch.bfloat16 else L.global_pool)(feats[m].data_ptr(), pl.data_ptr(), N, 512, st)
             pooled.append(pl)
         fused = torch.empty((B, 512), dtype=F32, device=self.device)
         L.head_sum(pooled[0].data_ptr(), pooled[1].data_ptr(), pooled[2].data_ptr(), xo.data_ptr(), fused.data_ptr(), B,
@@ -911,7 +976,7 @@ class TransFuser(nn.Module):
             logits = pred
         tape = None
         if record:
-            tape = (B, stem_ctx, layer_ctx, stage_ctx, (fused, h1, h2, [f.shape for f in feats], gru), gps)
+            tape = (B, stem_ctx, layer_ctx, stage_ctx, (fused, h1, h2, [f.shape for f in feats], gru, feats[0].dtype), gps)
         return logits, tape
 
     # ================================================================ backward walk =============
@@ -980,6 +1045,8 @@ class TransFuser(nn.Module):
         self._wg_launch(lambda: ops.linear_wgrad(x, dy, gw, self._ws, accumulate=accumulate, dbias_ptr=gb), (x, dy))
 
     def _block_bwd(self, blk, ctx, dout, need_dx=True):
+        if dout.dtype == torch.bfloat16:
+            return self._block_bwd16(blk, ctx, dout)
         x, c1, a1, s1, c2, s2, cd, sd, out, ud1, ud2 = ctx
         dc2, dres = self._bn_bwd(blk.bn2, dout, out, c2, s2, want_dres=True)
         self._wgrad_conv(blk.conv2, a1, dc2, 3, 1, 1)
@@ -1057,9 +1124,11 @@ class TransFuser(nn.Module):
         gpt = getattr(self.encoder, f"transformer{s}")
         vel = getattr(self.encoder, f"vel_emb{s}")
         dxo = torch.empty((B * T, C), dtype=F32, device=self.device)
+        f16 = dfeats_out[0].dtype == torch.bfloat16
         for m in range(3):
             N, H = fshapes[m][0], fshapes[m][1]
-            L.upsample_add_bwd(dfeats_out[m].data_ptr(), dxo.data_ptr(), N, H, C, fps[m], offs[m], T, st)
+            (L.bf16_upsample_add_bwd if f16 else L.upsample_add_bwd)(dfeats_out[m].data_ptr(), dxo.data_ptr(), N, H, C, fps[m],
+                                                                     offs[m], T, st)
         gsrc, bcast = dgps_tok
         L.gps_rows(gsrc.data_ptr(), dxo.data_ptr(), B, C, T, 1, 0, int(bcast), st)
         gfw, af = self._g(gpt.ln_f.weight)
@@ -1085,8 +1154,9 @@ class TransFuser(nn.Module):
         dfeats = []
         for m in range(3):
             N, H = fshapes[m][0], fshapes[m][1]
-            d = torch.empty(tuple(fshapes[m]), dtype=F32, device=self.device)
-            L.avgpool_tokens_bwd(dpre.data_ptr(), dfeats_out[m].data_ptr(), d.data_ptr(), N, H, C, fps[m], offs[m], T, st)
+            d = torch.empty(tuple(fshapes[m]), dtype=dfeats_out[m].dtype, device=self.device)
+            (L.bf16_avgpool_tokens_bwd if f16 else L.avgpool_tokens_bwd)(dpre.data_ptr(), dfeats_out[m].data_ptr(), d.data_ptr(),
+                                                                       N, H, C, fps[m], offs[m], T, st)
             dfeats.append(d)
         dgemb = torch.empty((B, 2, C), dtype=F32, device=self.device)
         L.gps_rows(dpre.data_ptr(), dgemb.data_ptr(), B, C, T, 0, 0, 0, st)
@@ -1109,8 +1179,9 @@ class TransFuser(nn.Module):
         bn = trunk.bn1
         gw_bn, a_bn = self._g(bn.weight)
         gb_bn, _ = self._g(bn.bias)
-        dc1 = ops.bn_bwd_maxpool(dpool, idx, c1, st1[0], st1[1], self._w(bn.weight), self._w(bn.bias), gw_bn, gb_bn,
-                                 self._ws, accumulate=bool(a_bn))
+        bwd_pool = ops.bn_bwd_maxpool_bf16in if dpool.dtype == torch.bfloat16 else ops.bn_bwd_maxpool
+        dc1 = bwd_pool(dpool, idx, c1, st1[0], st1[1], self._w(bn.weight), self._w(bn.bias), gw_bn, gb_bn,
+                       self._ws, accumulate=bool(a_bn))
         dwpad = torch.empty((64, 7, 7, 4), dtype=F32, device=self.device)
         gw, aw = self._g(trunk.conv1.weight)
 
@@ -1124,7 +1195,7 @@ class TransFuser(nn.Module):
         st = ops._stream()
         cfg = self.config
         B, stem_ctx, layer_ctx, stage_ctx, head, gps = tape
-        fused, h1, h2, fshapes, gru = head
+        fused, h1, h2, fshapes, gru, fdtype = head
         self._begin_backward()
         if gru is not None:  # back through the GRU head: dpred (B, pred_len, 64) -> gradient of the join output
             z0, saved = gru
@@ -1162,9 +1233,10 @@ class TransFuser(nn.Module):
         trunks = self._trunks()
         dfeats = []
         for m in range(3):
-            d = torch.empty(tuple(fshapes[m]), dtype=F32, device=self.device)
+            d = torch.empty(tuple(fshapes[m]), dtype=fdtype, device=self.device)
             fps = cfg.n_views * S if m == 0 else S
-            L.head_bwd(dfused.data_ptr(), d.data_ptr(), fshapes[m][0], 512, fps, st)
+            (L.bf16_head_bwd if fdtype == torch.bfloat16 else L.head_bwd)(dfused.data_ptr(), d.data_ptr(), fshapes[m][0], 512,
+                                                                        fps, st)
             dfeats.append(d)
         dgps = (dfused, True)
         for s in range(4, 0, -1):

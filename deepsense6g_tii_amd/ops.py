@@ -497,3 +497,55 @@ def attention_bwd_bf16(q, k, v, o16, d_o, lse, B, T, nh, ws: Workspace, drop_p=0
     lib().attention_bwd_bf16(_p(q), _p(k), _p(v), _p(o16), _p(d_o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, T, nh,
                              C // nh, ldq, C, ldd, float(drop_p), seed, seed_off, ws.ptr, ws.nbytes, _stream())
     return dq, dk, dv
+
+
+# ---- bf16-storage path: BatchNorm / pooling / resampling on bf16 feature maps (statistics and arithmetic fp32) ----
+def bf16_bn_stats(x2d_rows, C, x, mean, invstd, rm_ptr, rv_ptr, ws: Workspace, eps=1e-5, momentum=0.1):
+    _chk16(x)
+    lib().bf16_bn_stats(_p(x), x2d_rows, C, eps, momentum, _p(mean), _p(invstd), rm_ptr, rv_ptr, ws.ptr, ws.nbytes, _stream())
+
+
+def bf16_bn_apply(x, mean, invstd, gamma_ptr, beta_ptr, relu, residual=None):
+    _chk16(x)
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    if residual is not None:
+        _chk16(residual, *x.shape)
+    lib().bf16_bn_apply(_p(x), _p(mean), _p(invstd), gamma_ptr, beta_ptr, _p(residual), _p(y), x.numel() // C, C, int(relu),
+                        _stream())
+    return y
+
+
+def bf16_bn_bwd(dy, y_mask, x, mean, invstd, gamma_ptr, dgamma_ptr, dbeta_ptr, ws: Workspace, want_dres=False,
+                accumulate=False, relu_beta_ptr=0):
+    _chk16(dy, *x.shape)
+    _chk16(x)
+    if y_mask is not None:
+        _chk16(y_mask, *x.shape)
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    lib().bf16_bn_bwd(_p(dy), _p(y_mask), _p(x), _p(mean), _p(invstd), gamma_ptr, relu_beta_ptr, _p(dx), dgamma_ptr, dbeta_ptr,
+                      _p(dres), x.numel() // C, C, int(accumulate), ws.ptr, ws.nbytes, _stream())
+    return dx, dres
+
+
+def bn_relu_maxpool_bf16out(x, mean, invstd, gamma_ptr, beta_ptr):
+    """the stem's BN -> ReLU -> MaxPool of the fp32 conv output, pooled tensor written as bf16"""
+    N, H, W, C = x.shape
+    _chk(x)
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((N, Ho, Wo, C), dtype=BF16, device=x.device)
+    idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+    lib().bn_relu_maxpool3x3s2_fwd_bf16out(_p(x), _p(mean), _p(invstd), gamma_ptr, beta_ptr, _p(y), _p(idx), N, H, W, C, _stream())
+    return y, idx
+
+
+def bn_bwd_maxpool_bf16in(dpool, idx, x, mean, invstd, gamma_ptr, beta_ptr, dgamma_ptr, dbeta_ptr, ws: Workspace, accumulate=False):
+    N, H, W, C = x.shape
+    _chk(x)
+    _chk16(dpool, N, (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1, C)
+    dx = torch.empty_like(x)
+    lib().bn_bwd_maxpool_bf16in(_p(dpool), _p(idx), _p(x), _p(mean), _p(invstd), gamma_ptr, beta_ptr, _p(dx), dgamma_ptr,
+                                dbeta_ptr, N, H, W, C, int(accumulate), ws.ptr, ws.nbytes, _stream())
+    return dx

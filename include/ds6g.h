@@ -102,7 +102,7 @@ int ds6g_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, 
  * no mixed precision, train2_seq.py:111-116).  x / dy / w: bf16; y / dx: bf16 when out16 else fp32; dw / dbias / bias /
  * residual: fp32.  Tiles travel HBM -> LDS as bf16 by LDS-DMA and feed v_mfma_f32_32x32x16_bf16 without conversion.
  * Shape limits (every layer of the model but the 4-channel stems): the reduction channel count is a multiple of 64, the
- * other a multiple of 8; dgrad: stride 1; wgrad: Wo % 64 == 0, or 64 % Wo == 0 with Ho % (64 / Wo) == 0, or a Linear. */
+ * other a multiple of 8; dgrad: stride 1, or 2 with even H, W; wgrad: Wo % 64 == 0, or 64 % Wo == 0 with Ho % (64 / Wo) == 0, or a Linear. */
 int ds6g_bf16_conv2d_fwd(const void* x, const void* w, void* y, int out16, int N, int H, int W, int C, int K, int R, int S,
                          int stride, int pad, void* stream);
 int ds6g_bf16_conv2d_dgrad(const void* dy, const void* w, void* dx, int out16, int N, int H, int W, int C, int K, int R,
@@ -144,6 +144,15 @@ int ds6g_layernorm_bwd(const float* dy, const float* x, const float* mean, const
                        const float* add, float* dx, float* dgamma, float* dbeta, int M, int C,
                        int accumulate_param_grads, float* dx_drop, float drop_p, uint64_t seed, uint64_t seed_off,
                        void* ws, size_t ws_bytes, void* stream);
+/* bf16-storage path of BatchNorm2d: conv outputs, activations and their gradients are bf16 in HBM (x / residual / y /
+ * dy / y_mask / dx / dres), the statistics, running stats, parameter gradients and every reduction stay fp32 / fp64. */
+int ds6g_bf16_bn_stats(const void* x, long M, int C, float eps, float momentum, float* mean, float* invstd,
+                       float* running_mean, float* running_var, void* ws, size_t ws_bytes, void* stream);
+int ds6g_bf16_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                       const void* residual, void* y, long M, int C, int relu, void* stream);
+int ds6g_bf16_bn_bwd(const void* dy, const void* y_mask, const void* x, const float* mean, const float* invstd,
+                     const float* gamma, const float* relu_beta, void* dx, float* dgamma, float* dbeta, void* dres, long M,
+                     int C, int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream);
 /* bf16-storage path (GEMM-facing tensors are bf16; statistics, the residual stream and all arithmetic stay fp32):
  * layernorm_fwd_bf16out writes y as bf16; layernorm_bwd_bf16 reads dy as bf16 (dy16) or fp32, writes dx fp32 and dx_drop
  * (nullable) = dropout(dx) as bf16 (drop_p = 0: a bf16 copy of dx, the next GEMM's operand). */
@@ -240,6 +249,28 @@ int ds6g_bn_relu_maxpool3x3s2_fwd(const float* x, const float* mean, const float
 int ds6g_bn_bwd_maxpool(const float* dpool, const uint8_t* idx, const float* x, const float* mean, const float* invstd,
                         const float* gamma, const float* relu_beta, float* dx, float* dgamma, float* dbeta, int N, int H,
                         int W, int C, int accumulate_param_grads, void* ws, size_t ws_bytes, void* stream);
+/* bf16-storage path: the 4-channel stem keeps the fp32-storage conv kernels (x, dx fp32); its pooled output is written as
+ * bf16 (first tensor of the bf16 trunk) and the gradient of the pooled tensor arrives as bf16 */
+int ds6g_bn_relu_maxpool3x3s2_fwd_bf16out(const float* x, const float* mean, const float* invstd, const float* gamma,
+                                          const float* beta, void* y, uint8_t* idx, int N, int H, int W, int C,
+                                          void* stream);
+int ds6g_bn_bwd_maxpool_bf16in(const void* dpool, const uint8_t* idx, const float* x, const float* mean,
+                               const float* invstd, const float* gamma, const float* relu_beta, float* dx, float* dgamma,
+                               float* dbeta, int N, int H, int W, int C, int accumulate_param_grads, void* ws,
+                               size_t ws_bytes, void* stream);
+/* bf16-storage path of the pooling / resampling / head kernels below: feature maps (feat, out, dfeat, dout) bf16, tokens /
+ * pos_emb / pooled vectors fp32 */
+int ds6g_bf16_avgpool_tokens_fwd(const void* feat, const float* pos_emb, float* tokens, int N, int H, int C,
+                                 int frames_per_sample, int mod_off, int T, float drop_p, uint64_t seed,
+                                 uint64_t seed_off, void* stream);
+int ds6g_bf16_avgpool_tokens_bwd(const float* dtok, const void* dfeat_in, void* dfeat, int N, int H, int C,
+                                 int frames_per_sample, int mod_off, int T, void* stream);
+int ds6g_bf16_upsample_add_fwd(const void* feat, const float* tokens, void* out, int N, int H, int C,
+                               int frames_per_sample, int mod_off, int T, void* stream);
+int ds6g_bf16_upsample_add_bwd(const void* dout, float* dtok, int N, int H, int C, int frames_per_sample, int mod_off,
+                               int T, void* stream);
+int ds6g_bf16_global_pool(const void* feat, float* pooled, int N, int C, void* stream);
+int ds6g_bf16_head_bwd(const float* dfused, void* dfeat, int N, int C, int frames_per_sample, void* stream);
 /* AdaptiveAvgPool2d((8,8)) + token pack + pos_emb + embd dropout: model2_seq.py:414,515-517,261-272 */
 int ds6g_avgpool_tokens_fwd(const float* feat, const float* pos_emb, float* tokens, int N, int H, int C,
                             int frames_per_sample, int mod_off, int T, float drop_p, uint64_t seed,

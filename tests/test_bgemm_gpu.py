@@ -98,13 +98,15 @@ def test_bf16_linear_dropout_epilogue_draws_the_fp32_paths_mask(dev):
 CONV = [
     # N, H, W, C, K, R, stride, pad
     (2, 16, 16, 64, 64, 3, 1, 1),
-    (3, 16, 16, 64, 128, 3, 2, 1),      # strided forward / wgrad (its dgrad stays on the fp32-storage kernel)
+    (3, 16, 16, 64, 128, 3, 2, 1),      # strided: the data gradient runs per input-pixel parity class
     (2, 16, 16, 64, 128, 1, 2, 0),
     (5, 8, 8, 256, 512, 3, 1, 1),
     (1, 12, 32, 128, 192, 3, 1, 1),     # ragged M, N not multiples of the tiles
     (10, 64, 64, 64, 64, 3, 1, 1),      # 128 x 128 tiles
     (4, 32, 32, 128, 128, 3, 1, 1),
     (60, 8, 8, 512, 512, 3, 1, 1),      # benchmark batch, whole images per wgrad k-tile
+    (6, 32, 32, 128, 256, 3, 2, 1),
+    (6, 16, 16, 256, 512, 1, 2, 0),     # 1x1 / 2 downsample: three of the four parity classes receive nothing
 ]
 
 
@@ -124,7 +126,7 @@ def test_bf16_conv_fwd_dgrad_wgrad(dev, case):
     ws = ops.Workspace(dev, 512 << 20)
     close16(nchw(ops.bf16_conv2d_fwd(xg, wg.data_ptr(), K, R, R, st, pad)), y.detach())
     close32(nchw(ops.bf16_conv2d_fwd(xg, wg.data_ptr(), K, R, R, st, pad, out16=False)), y.detach())
-    if st == 1:
+    if True:
         close16(nchw(ops.bf16_conv2d_dgrad(dyg, wg.data_ptr(), tuple(xg.shape), R, R, st, pad)), x.grad)
         base = r16(torch.randn(xg.shape, generator=g))
         acc = base.cuda().clone()
@@ -146,6 +148,143 @@ def test_bf16_entry_points_reject_unsupported_shapes(dev):
     w = torch.zeros(64, 48, dtype=BF, device=dev)
     with pytest.raises(Ds6gError):
         ops.bf16_linear_fwd(x, w.data_ptr(), 0, 64)
-    dy = torch.zeros(2, 8, 8, 64, dtype=BF, device=dev)
-    with pytest.raises(Ds6gError):                       # strided data gradient: not in this kernel
-        ops.bf16_conv2d_dgrad(dy, w.data_ptr(), (2, 16, 16, 64), 3, 3, 2, 1)
+    dy = torch.zeros(2, 4, 4, 64, dtype=BF, device=dev)
+    with pytest.raises(Ds6gError):                       # stride-2 data gradient needs even H, W (parity classes)
+        ops.bf16_conv2d_dgrad(dy, w.data_ptr(), (2, 7, 7, 64), 3, 3, 2, 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the non-GEMM kernels of the bf16-storage path: same arithmetic (fp32) as their fp32-storage twins - which are checked
+# against torch in test_ops_gpu.py - reading / writing bf16.  Reference = the fp32 twin on the up-cast inputs; a bf16 output
+# must equal it within one rounding, an fp32 output (statistics, parameter gradients, tokens) within fp32 noise.
+def same32(a, b, tol=2e-6):
+    """fp32 results of the two template instantiations of one kernel: identical up to the compiler's fma contraction"""
+    return (a.double() - b.double()).abs().max().item() <= tol * b.double().abs().max().item() + 1e-30
+
+
+def one_rounding(a16, ref32, extra=1e-6):
+    a, b = a16.double().cpu(), ref32.double().cpu()
+    bound = b.abs() * 2.0 ** -8 + extra * b.abs().max() + 1e-30
+    assert ((a - b).abs() <= bound).all(), ((a - b).abs() - bound).max().item()
+
+
+@pytest.mark.parametrize("M,C", [(60 * 16 * 16, 64), (3 * 5 * 7, 128), (5000, 512)])
+def test_bf16_batchnorm_fwd_bwd(dev, M, C):
+    from deepsense6g_tii_amd import ops
+    g = torch.Generator().manual_seed(M + C)
+    x = r16(torch.randn(M, C, generator=g) * 2 + 0.5).cuda()
+    res = r16(torch.randn(M, C, generator=g)).cuda()
+    dy = r16(torch.randn(M, C, generator=g)).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    beta = torch.randn(C, generator=g).cuda()
+    ws = ops.Workspace(dev, 64 << 20)
+    st16, st32 = torch.empty(2, C, device=dev), torch.empty(2, C, device=dev)
+    rm16, rv16, rm32, rv32 = (torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.zeros(C, device=dev), torch.ones(C, device=dev))
+    ops.bf16_bn_stats(M, C, x, st16[0], st16[1], rm16.data_ptr(), rv16.data_ptr(), ws)
+    ops.bn_stats(M, C, x.float(), st32[0], st32[1], rm32.data_ptr(), rv32.data_ptr(), ws)
+    assert same32(st16, st32) and same32(rm16, rm32) and same32(rv16, rv32)   # same fp64 reduction of the same values
+    y16 = ops.bf16_bn_apply(x, st16[0], st16[1], gamma.data_ptr(), beta.data_ptr(), True, res)
+    y32 = ops.bn_apply(x.float(), st32[0], st32[1], gamma.data_ptr(), beta.data_ptr(), True, res.float())
+    one_rounding(y16, y32)
+    # backward with the activation as ReLU mask and a residual branch
+    dg16, db16, dg32, db32 = (torch.empty(C, device=dev) for _ in range(4))
+    dx16, dr16 = ops.bf16_bn_bwd(dy, y16, x, st16[0], st16[1], gamma.data_ptr(), dg16.data_ptr(), db16.data_ptr(), ws, want_dres=True)
+    dx32, dr32 = ops.bn_bwd(dy.float(), y16.float(), x.float(), st32[0], st32[1], gamma.data_ptr(), dg32.data_ptr(), db32.data_ptr(),
+                            ws, want_dres=True)
+    one_rounding(dx16, dx32)
+    assert torch.equal(dr16.float(), dr32)
+    assert same32(dg16, dg32) and same32(db16, db32)
+    # BN -> ReLU without residual: mask recomputed from x
+    dx16b, _ = ops.bf16_bn_bwd(dy, None, x, st16[0], st16[1], gamma.data_ptr(), dg16.data_ptr(), db16.data_ptr(), ws,
+                               relu_beta_ptr=beta.data_ptr())
+    dx32b, _ = ops.bn_bwd(dy.float(), None, x.float(), st32[0], st32[1], gamma.data_ptr(), dg32.data_ptr(), db32.data_ptr(), ws,
+                          relu_beta_ptr=beta.data_ptr())
+    one_rounding(dx16b, dx32b)
+    assert same32(dg16, dg32) and same32(db16, db32)
+
+
+def test_bf16_stem_pool_layernorm_attention_and_spatial_variants(dev):
+    from deepsense6g_tii_amd import ops
+    from deepsense6g_tii_amd._lib import lib
+    L = lib()
+    st = ops._stream()
+    g = torch.Generator().manual_seed(3)
+    ws = ops.Workspace(dev, 256 << 20)
+    # stem: BN -> ReLU -> max-pool of an fp32 conv output, pooled tensor bf16; backward from a bf16 pool gradient
+    N, H, W, C = 3, 16, 16, 64
+    x = torch.randn(N, H, W, C, generator=g).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    stt = torch.empty(2, C, device=dev)
+    ops.bn_stats(N * H * W, C, x, stt[0], stt[1], 0, 0, ws)
+    p16, idx16 = ops.bn_relu_maxpool_bf16out(x, stt[0], stt[1], gamma.data_ptr(), beta.data_ptr())
+    p32, idx32 = ops.bn_relu_maxpool(x, stt[0], stt[1], gamma.data_ptr(), beta.data_ptr())
+    assert torch.equal(idx16, idx32)
+    one_rounding(p16, p32)
+    dp = r16(torch.randn(p32.shape, generator=g)).cuda()
+    dg16, db16, dg32, db32 = (torch.empty(C, device=dev) for _ in range(4))
+    dxa = ops.bn_bwd_maxpool_bf16in(dp, idx16, x, stt[0], stt[1], gamma.data_ptr(), beta.data_ptr(), dg16.data_ptr(), db16.data_ptr(), ws)
+    dxb = ops.bn_bwd_maxpool(dp.float(), idx32, x, stt[0], stt[1], gamma.data_ptr(), beta.data_ptr(), dg32.data_ptr(), db32.data_ptr(), ws)
+    assert same32(dxa, dxb) and same32(dg16, dg32)
+    # LayerNorm: bf16 output; backward from bf16 / fp32 dy with a bf16 dropout(dx)
+    M, Cl = 962, 256
+    xl = torch.randn(M, Cl, generator=g).cuda()
+    gl, bl = (torch.rand(Cl, generator=g) + 0.5).cuda(), torch.randn(Cl, generator=g).cuda()
+    y16, m16, r16_ = ops.layernorm_fwd_bf16(xl, gl.data_ptr(), bl.data_ptr())
+    y32, m32, r32 = ops.layernorm_fwd(xl, gl.data_ptr(), bl.data_ptr())
+    assert same32(m16, m32) and same32(r16_, r32)
+    one_rounding(y16, y32)
+    add = torch.randn(M, Cl, generator=g).cuda()
+    for dy in (r16(torch.randn(M, Cl, generator=g)).cuda(), torch.randn(M, Cl, generator=g).cuda()):
+        ga, ba, gb, bb = (torch.empty(Cl, device=dev) for _ in range(4))
+        dx16, dd16 = ops.layernorm_bwd_bf16(dy, xl, m16, r16_, gl.data_ptr(), ga.data_ptr(), ba.data_ptr(), ws, add=add,
+                                            drop=(0.1, 5, 2048))
+        dx32, dd32 = ops.layernorm_bwd(dy.float(), xl, m32, r32, gl.data_ptr(), gb.data_ptr(), bb.data_ptr(), ws, add=add,
+                                       drop=(0.1, 5, 2048))
+        assert same32(dx16, dx32) and same32(ga, gb, 1e-5) and same32(ba, bb, 1e-5)
+        one_rounding(dd16, dd32)
+        assert torch.equal(dd16 == 0, dd32 == 0)                      # the same dropout mask
+    # attention: bf16 o / dq / dk / dv from fp32 q, k, v, dO
+    B, T, nh, hd = 2, 333, 4, 32
+    Ca = nh * hd
+    q, k, v, do = (torch.randn(B * T, Ca, generator=g).cuda() for _ in range(4))
+    big = ops.Workspace(dev, int(L.attention_workspace_bytes(B, T, nh, hd, Ca)) + (64 << 20))
+    o32, lse32 = ops.attention_fwd(q, k, v, B, T, nh, big, 0.1, 9, 4096)
+    o16, lse16 = ops.attention_fwd_bf16out(q, k, v, B, T, nh, big, 0.1, 9, 4096)
+    assert same32(lse16, lse32)
+    one_rounding(o16, o32)
+    ref = ops.attention_bwd(q, k, v, o16.float(), do, lse32, B, T, nh, big, 0.1, 9, 4096)
+    got = ops.attention_bwd_bf16(q, k, v, o16, do, lse16, B, T, nh, big, 0.1, 9, 4096)
+    for a, b in zip(got, ref):
+        one_rounding(a, b, extra=2e-5)
+    # pooling / resampling / head on bf16 feature maps
+    Nf, Hf, Cf, fps, T2 = 10, 16, 128, 5, 962
+    feat = r16(torch.randn(Nf, Hf, Hf, Cf, generator=g)).cuda()
+    pos = torch.randn(T2, Cf, generator=g).cuda()
+    tok16, tok32 = torch.zeros(2, T2, Cf, device=dev), torch.zeros(2, T2, Cf, device=dev)
+    L.bf16_avgpool_tokens_fwd(feat.data_ptr(), pos.data_ptr(), tok16.data_ptr(), Nf, Hf, Cf, fps, 320, T2, 0.1, 7, 0, st)
+    L.avgpool_tokens_fwd(feat.float().data_ptr(), pos.data_ptr(), tok32.data_ptr(), Nf, Hf, Cf, fps, 320, T2, 0.1, 7, 0, st)
+    assert same32(tok16, tok32)
+    xo = torch.randn(2 * T2, Cf, generator=g).cuda()
+    o16_, o32_ = torch.empty_like(feat), torch.empty(feat.shape, device=dev)
+    L.bf16_upsample_add_fwd(feat.data_ptr(), xo.data_ptr(), o16_.data_ptr(), Nf, Hf, Cf, fps, 320, T2, st)
+    L.upsample_add_fwd(feat.float().data_ptr(), xo.data_ptr(), o32_.data_ptr(), Nf, Hf, Cf, fps, 320, T2, st)
+    one_rounding(o16_, o32_)
+    dtok16, dtok32 = torch.zeros(2 * T2, Cf, device=dev), torch.zeros(2 * T2, Cf, device=dev)
+    L.bf16_upsample_add_bwd(feat.data_ptr(), dtok16.data_ptr(), Nf, Hf, Cf, fps, 320, T2, st)
+    L.upsample_add_bwd(feat.float().data_ptr(), dtok32.data_ptr(), Nf, Hf, Cf, fps, 320, T2, st)
+    assert same32(dtok16, dtok32)
+    d16, d32 = torch.empty_like(feat), torch.empty(feat.shape, device=dev)
+    L.bf16_avgpool_tokens_bwd(xo.data_ptr(), feat.data_ptr(), d16.data_ptr(), Nf, Hf, Cf, fps, 320, T2, st)
+    L.avgpool_tokens_bwd(xo.data_ptr(), feat.float().data_ptr(), d32.data_ptr(), Nf, Hf, Cf, fps, 320, T2, st)
+    one_rounding(d16, d32)
+    f8 = r16(torch.randn(Nf, 8, 8, 512, generator=g)).cuda()
+    pl16, pl32 = torch.empty(Nf, 512, device=dev), torch.empty(Nf, 512, device=dev)
+    L.bf16_global_pool(f8.data_ptr(), pl16.data_ptr(), Nf, 512, st)
+    L.global_pool(f8.float().data_ptr(), pl32.data_ptr(), Nf, 512, st)
+    assert same32(pl16, pl32)
+    dfu = torch.randn(2, 512, generator=g).cuda()
+    h16, h32 = torch.empty_like(f8), torch.empty(f8.shape, device=dev)
+    L.bf16_head_bwd(dfu.data_ptr(), h16.data_ptr(), Nf, 512, fps, st)
+    L.head_bwd(dfu.data_ptr(), h32.data_ptr(), Nf, 512, fps, st)
+    one_rounding(h16, h32)
+    torch.cuda.synchronize()
