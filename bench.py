@@ -224,6 +224,10 @@ def main():
     ap.add_argument("--image-only", action="store_true",
                     help="BASELINE configs[1]: zeroed LiDAR / radar inputs - the reference's own 'zerolike' missing-modality "
                          "semantics (mambafuser_seq.py:384-391); same kernels and FLOPs, other input statistics")
+    ap.add_argument("--graph", type=int, default=1,
+                    help="1 (default, single process): the timed steps replay ONE captured HIP graph of the whole iteration "
+                         "(train.CapturedTrainStep, bit-identical to the eager iteration); 0: eager launches.  Data-parallel "
+                         "runs (--gpus > 1) are always eager (bucketed all-reduce issued from the backward walk)")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the three trunks on one stream (per-kernel profiling: durations are not overlapped)")
     ap.add_argument("--debug-flags", type=lambda v: int(v, 0), default=0, help="ds6g_set_debug_flags (tuning experiments)")
@@ -236,7 +240,7 @@ def main():
     from deepsense6g_tii_amd import ops
     from deepsense6g_tii_amd.model import GlobalConfig, TransFuser
     from deepsense6g_tii_amd.synthetic import make_batch
-    from deepsense6g_tii_amd.train import EMA, FusedAdamW, train_iteration
+    from deepsense6g_tii_amd.train import EMA, CapturedTrainStep, FusedAdamW, train_iteration
 
     # the process group first: under torch.distributed.run nothing may touch the GPU before init_process_group
     rank, world, local = ddist.init_distributed()
@@ -275,12 +279,18 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    use_graph = bool(args.graph) and world == 1
+    if use_graph:
+        stepper = CapturedTrainStep(model, opt, batch, ema, warmup=2)
+        run_step = stepper.step
+    else:
+        run_step = lambda: train_iteration(model, opt, batch, ema, reducer)  # noqa: E731
     for _ in range(args.warmup):
-        loss, _ = train_iteration(model, opt, batch, ema, reducer)
+        loss, _ = run_step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, _ = train_iteration(model, opt, batch, ema, reducer)
+        loss, _ = run_step()
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -369,7 +379,8 @@ def main():
                                    f"5x(3+1+2)x256x256 + 2x2 GPS per sample, bs={args.batch} per GPU, sigmoid focal loss, "
                                    "AdamW, train-mode BN, dropout 0.1",
                        "global_batch": args.batch * world, "seq_len": cfg.seq_len,
-                       "parallelism": f"dp{world}", "ema": bool(args.ema)},
+                       "parallelism": f"dp{world}", "ema": bool(args.ema),
+                       "launch": "one HIP graph per step" if use_graph else "eager"},
             "loss": final_loss,
             "algorithmic_gflop_per_sample": 559.3,
             "model_tflops": value * 559.3e9 / 1e12,

@@ -49,6 +49,7 @@ struct AttnParams {
     float dscale;
     uint64_t seed;
     uint64_t seed_off;
+    const uint64_t* salt;   // device-resident addend of seed_off (nullable), see ds6g_set_dropout_salt
     // backward hand-over (see attn_bwd_dkv_kernel): 32 x 32 tiles of dS / dropped P in the dK/dV kernel's accumulator
     // order, [b*nh + h][query tile < nkg][key group < nkg][reg / 4][lane 64][reg % 4]
     float* hs;
@@ -309,6 +310,7 @@ __device__ __forceinline__ void store_rows(const f32x16* acc, float* base, int l
     }                                                                                                  \
     const int h = by_ % p.nh, split = by_ / p.nh, b = bz_;                                             \
     const int T = p.T;                                                                                 \
+    [[maybe_unused]] const uint64_t seed_off_ = p.seed_off + (p.salt ? *p.salt : (uint64_t)0);         \
     const long head_off = (long)b * T * p.ld + h * HD;                                                 \
     [[maybe_unused]] const long head_offq = (long)b * T * p.ldq + h * HD;                                            \
     [[maybe_unused]] const long head_offd = (long)b * T * p.ldd + h * HD;                              \
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = key0 + krow16(r, half);
-                s[r] = ds6g_keep(p.seed, p.seed_off + (uint64_t)(drop_row + key), p.thr) ? s[r] * p.dscale : 0.f;
+                s[r] = ds6g_keep(p.seed, seed_off_ + (uint64_t)(drop_row + key), p.thr) ? s[r] * p.dscale : 0.f;
             }
         }
         mma_dims<HD, BF>(oacc, Vc, s, dtab);
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
             const int key = key0 + krow16(r, half);
             const float pr = (key < T) ? __expf(s[r] - lse) : 0.f;
             float g = dp[r];
-            if (p.thr) g = ds6g_keep(p.seed, p.seed_off + (uint64_t)(drop_row + key), p.thr) ? g * p.dscale : 0.f;
+            if (p.thr) g = ds6g_keep(p.seed, seed_off_ + (uint64_t)(drop_row + key), p.thr) ? g * p.dscale : 0.f;
             s[r] = pr * (g - delta) * p.scale;  // dS (scaled)
         }
         mma_dims<HD, BF>(dq, Kc, s, dtab);
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(256, (HD <= 32 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
             float pr = __expf(s[r] * p.scale - lse_s[buf][ql]);  // lse = +inf for q >= T -> 0
             float g = dp[r];
             if (p.thr) {
-                const bool keep = ds6g_keep(p.seed, p.seed_off + (uint64_t)((stat_base + q0 + ql) * (long)T + key), p.thr);
+                const bool keep = ds6g_keep(p.seed, seed_off_ + (uint64_t)((stat_base + q0 + ql) * (long)T + key), p.thr);
                 g = keep ? g * p.dscale : 0.f;
                 dp[r] = pr * (g - delta_s[buf][ql]) * p.scale;
                 pr = keep ? pr * p.dscale : 0.f;
@@ -895,7 +897,7 @@ static int attention_fwd_impl(const float* q, const float* k, const float* v, fl
     p.bytes = (unsigned)(slab * sizeof(float)); p.slab = slab;
     p.bytes_q = (unsigned)((((size_t)B * T - 1) * ld_qkv + nh * hd) * sizeof(float));
     p.scale = 1.0f / sqrtf((float)hd);
-    p.thr = ds6g_drop_threshold(drop_p); p.dscale = 1.f / (1.f - drop_p); p.seed = seed; p.seed_off = seed_off;
+    p.thr = ds6g_drop_threshold(drop_p); p.dscale = 1.f / (1.f - drop_p); p.seed = seed; p.seed_off = seed_off; p.salt = g_ds6g_salt;
     const int ntiles = cdiv(T, 32);
     const int qblocks = cdiv(T, 128);
     const int per_cu = 3;  // measured (tools/bench_attn.py, DBG bits 20-23): 3 is best or tied for every head dim
@@ -950,7 +952,7 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
     p.bytes = (unsigned)(slab * sizeof(float)); p.slab = slab;
     p.bytes_q = (unsigned)((((size_t)B * T - 1) * ld_qkv + nh * hd) * sizeof(float));
     p.scale = 1.0f / sqrtf((float)hd);
-    p.thr = ds6g_drop_threshold(drop_p); p.dscale = 1.f / (1.f - drop_p); p.seed = seed; p.seed_off = seed_off;
+    p.thr = ds6g_drop_threshold(drop_p); p.dscale = 1.f / (1.f - drop_p); p.seed = seed; p.seed_off = seed_off; p.salt = g_ds6g_salt;
     const int ntiles = cdiv(T, 32);
     const int blocks128 = cdiv(T, 128);
     const int cols4 = nh * hd / 4;

@@ -54,6 +54,7 @@ struct BgemmParams {
     uint32_t drop_thr;
     float drop_scale;
     uint64_t seed, seed_off;
+    const uint64_t* salt;    // device-resident addend of seed_off (nullable), see ds6g_set_dropout_salt
     int k_per_split;      // multiple of 64
     size_t split_stride;
     int tiles_n;
@@ -74,6 +75,7 @@ __device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(u
 template <int MODE, int BM, int BN, int OUT16, int EPI>
 __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
     BgemmParams p = pin;
+    if (EPI && p.drop_thr && p.salt) p.seed_off += *p.salt;
     if (MODE == B_DGRAD && pin.nclass > 1) {
         const int ph = blockIdx.y >> 1, pw = blockIdx.y & 1;
         p.h0 = ph;
@@ -630,7 +632,7 @@ int ds6g_bf16_linear_fwd(const void* x, const void* w, const float* bias, void* 
     p.a_src = (const __bf16*)x; p.b_src = (const __bf16*)w; p.out = y; p.bias = bias; p.relu = relu; p.residual = residual;
     p.drop_thr = ds6g_drop_threshold(drop_p);
     p.drop_scale = 1.f / (1.f - drop_p);
-    p.seed = seed; p.seed_off = seed_off;
+    p.seed = seed; p.seed_off = seed_off; p.salt = g_ds6g_salt;
     p.a_bytes = (unsigned)((size_t)M * K * 2); p.b_bytes = (unsigned)((size_t)N * K * 2);
     p.Mg = M; p.Ng = N; p.Kg = K;
     return launch_bgemm<B_FWD>(p, out16, 1, pick_tile(M, N, 1), (hipStream_t)stream);

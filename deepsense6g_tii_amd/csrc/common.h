@@ -134,6 +134,11 @@ __device__ __forceinline__ f32x16 mfma_x6(const bf16x8& ah, const bf16x8& am, co
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Device-resident dropout salt (ds6g_set_dropout_salt): when set, every kernel that draws a dropout mask adds *salt to its
+// counter offset at RUN time, so a captured hipGraph of the training step draws fresh masks on every replay although its
+// launch arguments are frozen.  Thread-local: a caller thread sets it around its own launches (no process-wide state).
+extern thread_local const uint64_t* g_ds6g_salt;
+
 // Counter-based dropout RNG: keep(idx) is a pure function of (seed, idx), so backward kernels
 // regenerate the mask instead of storing it.  One round of a 32-bit integer finalizer (lowbias32) over the low
 // counter word, keyed by the seed and the high counter word (the attention kernels evaluate it T*T times per head

@@ -57,6 +57,7 @@ struct IgemmParams {
     float drop_scale;
     uint64_t seed;
     uint64_t seed_off;
+    const uint64_t* salt;  // device-resident addend of seed_off (nullable), see ds6g_set_dropout_salt
     int k_per_split;     // multiple of 16
     size_t split_stride; // elements between split-K slabs
     int tiles_n;
@@ -91,6 +92,7 @@ struct IgemmParams {
 template <int MODE, int BM, int BN, int EPI, int BK, int BF, int FAST>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams pin) {
     IgemmParams p = pin;
+    if (EPI && p.drop_thr && p.salt) p.seed_off += *p.salt;
     if (MODE == MODE_DGRAD && pin.nclass > 1) {
         // strided dgrad: blockIdx.y = input-pixel parity class (ph, pw); class (ph, pw) only sees the taps
         // r = (ph + pad) mod 2 (+2, ...), s likewise - all four classes of a layer run as ONE launch
@@ -1040,7 +1042,7 @@ int ds6g_linear_fwd(const float* x, const float* w, const float* bias, float* y,
     p.a_src = x; p.b_src = w; p.out = y; p.bias = bias; p.relu = relu; p.residual = residual;
     p.drop_thr = ds6g_drop_threshold(drop_p);
     p.drop_scale = 1.f / (1.f - drop_p);
-    p.seed = seed; p.seed_off = seed_off;
+    p.seed = seed; p.seed_off = seed_off; p.salt = g_ds6g_salt;
     const ConvBytes cb = conv_bytes(p);
     DS6G_CHECK_ARG(cb.ok);
     p.a_bytes = (unsigned)cb.x; p.b_bytes = (unsigned)cb.w;

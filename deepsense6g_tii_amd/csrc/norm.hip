@@ -318,7 +318,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      const float* __restrict__ gamma, const float* __restrict__ add,
                                                      float* __restrict__ dx, float* __restrict__ partial, int M,
                                                      TDD* __restrict__ dx_drop, uint32_t thr, float dscale,
-                                                     uint64_t seed, uint64_t seed_off) {
+                                                     uint64_t seed, uint64_t seed_off_in,
+                                                     const uint64_t* __restrict__ salt) {
+    const uint64_t seed_off = seed_off_in + ((salt && dx_drop) ? *salt : (uint64_t)0);
     using R = LnRow<C>;
     __shared__ float red[4][2][C];
     const int lane = threadIdx.x & 63;
@@ -534,10 +536,10 @@ static int ln_bwd_launch(const TDY* dy, const float* x, const float* mean, const
     float* partial = (float*)ws;
     dim3 grid(nblk), block(256);
     switch (C / 64) {
-        case 1: hipLaunchKernelGGL((ln_bwd_kernel<64, TDY, TDD>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off); break;
-        case 2: hipLaunchKernelGGL((ln_bwd_kernel<128, TDY, TDD>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off); break;
-        case 4: hipLaunchKernelGGL((ln_bwd_kernel<256, TDY, TDD>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off); break;
-        case 8: hipLaunchKernelGGL((ln_bwd_kernel<512, TDY, TDD>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off); break;
+        case 1: hipLaunchKernelGGL((ln_bwd_kernel<64, TDY, TDD>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off, g_ds6g_salt); break;
+        case 2: hipLaunchKernelGGL((ln_bwd_kernel<128, TDY, TDD>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off, g_ds6g_salt); break;
+        case 4: hipLaunchKernelGGL((ln_bwd_kernel<256, TDY, TDD>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off, g_ds6g_salt); break;
+        case 8: hipLaunchKernelGGL((ln_bwd_kernel<512, TDY, TDD>), grid, block, 0, st, dy, x, mean, rstd, gamma, add, dx, partial, M, dx_drop, thr, dscale, seed, seed_off, g_ds6g_salt); break;
         default: DS6G_CHECK_ARG(!"LayerNorm width must be 64/128/256/512");
     }
     DS6G_LAUNCH_CHECK();

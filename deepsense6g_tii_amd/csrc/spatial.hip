@@ -144,7 +144,9 @@ __global__ __launch_bounds__(256) void avgpool_tokens_fwd_kernel(const TF* __res
                                                                  const float* __restrict__ pos_emb,
                                                                  float* __restrict__ tokens, int N, int H, int C,
                                                                  int fps, int mod_off, int T, uint32_t thr,
-                                                                 float scale, uint64_t seed, uint64_t seed_off) {
+                                                                 float scale, uint64_t seed, uint64_t seed_off_in,
+                                                                 const uint64_t* __restrict__ salt) {
+    const uint64_t seed_off = seed_off_in + ((salt && thr) ? *salt : (uint64_t)0);
     const int cg = C >> 2;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)N * 64 * cg) return;
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(256) void avgpool_tokens_fwd_kernel(const TF* __res
 // GPS rows: tokens[b][T-2+j][c] = dropout(emb[b][j][c] + pos_emb[T-2+j][c])
 __global__ void gps_tokens_fwd_kernel(const float* __restrict__ emb, const float* __restrict__ pos_emb,
                                       float* __restrict__ tokens, int B, int C, int T, uint32_t thr, float scale,
-                                      uint64_t seed, uint64_t seed_off) {
+                                      uint64_t seed, uint64_t seed_off_in, const uint64_t* __restrict__ salt) {
+    const uint64_t seed_off = seed_off_in + ((salt && thr) ? *salt : (uint64_t)0);
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * 2 * C) return;
     const int c = (int)(i % C);
@@ -188,7 +191,9 @@ __global__ void gps_tokens_fwd_kernel(const float* __restrict__ emb, const float
 
 // dst[i] = keep(i) ? src[i]*scale : 0    (dropout forward on a buffer, or its backward on a gradient)
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ src, float* __restrict__ dst, long n4,
-                                                      uint32_t thr, float scale, uint64_t seed, uint64_t seed_off) {
+                                                      uint32_t thr, float scale, uint64_t seed, uint64_t seed_off_in,
+                                                      const uint64_t* __restrict__ salt) {
+    const uint64_t seed_off = seed_off_in + ((salt && thr) ? *salt : (uint64_t)0);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         f32x4 v = *reinterpret_cast<const f32x4*>(src + i * 4);
 #pragma unroll
@@ -483,7 +488,7 @@ int ds6g_avgpool_tokens_fwd(const float* feat, const float* pos_emb, float* toke
     DS6G_CHECK_ARG(feat && pos_emb && tokens && C % 4 == 0 && H % 8 == 0 && N % frames_per_sample == 0);
     hipLaunchKernelGGL((avgpool_tokens_fwd_kernel<float>), dim3(grid1((long)N * 64 * (C / 4))), dim3(256), 0,
                        (hipStream_t)stream, feat, pos_emb, tokens, N, H, C, frames_per_sample, mod_off, T,
-                       ds6g_drop_threshold(drop_p), 1.f / (1.f - drop_p), seed, seed_off);
+                       ds6g_drop_threshold(drop_p), 1.f / (1.f - drop_p), seed, seed_off, g_ds6g_salt);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }
@@ -493,7 +498,7 @@ int ds6g_gps_tokens_fwd(const float* emb, const float* pos_emb, float* tokens, i
     DS6G_ENTER();
     DS6G_CHECK_ARG(emb && pos_emb && tokens);
     hipLaunchKernelGGL(gps_tokens_fwd_kernel, dim3(grid1((long)B * 2 * C)), dim3(256), 0, (hipStream_t)stream, emb,
-                       pos_emb, tokens, B, C, T, ds6g_drop_threshold(drop_p), 1.f / (1.f - drop_p), seed, seed_off);
+                       pos_emb, tokens, B, C, T, ds6g_drop_threshold(drop_p), 1.f / (1.f - drop_p), seed, seed_off, g_ds6g_salt);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }
@@ -503,7 +508,7 @@ int ds6g_dropout(const float* src, float* dst, long n, float drop_p, uint64_t se
     DS6G_ENTER();
     DS6G_CHECK_ARG(src && dst && n % 4 == 0 && drop_p >= 0.f && drop_p < 1.f);
     hipLaunchKernelGGL(dropout_kernel, dim3(grid_stride(n / 4)), dim3(256), 0, (hipStream_t)stream, src, dst, n / 4,
-                       ds6g_drop_threshold(drop_p), 1.f / (1.f - drop_p), seed, seed_off);
+                       ds6g_drop_threshold(drop_p), 1.f / (1.f - drop_p), seed, seed_off, g_ds6g_salt);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }
@@ -628,7 +633,7 @@ int ds6g_bf16_avgpool_tokens_fwd(const void* feat, const float* pos_emb, float* 
     DS6G_CHECK_ARG(feat && pos_emb && tokens && C % 4 == 0 && H % 8 == 0 && N % frames_per_sample == 0);
     hipLaunchKernelGGL((avgpool_tokens_fwd_kernel<__bf16>), dim3(grid1((long)N * 64 * (C / 4))), dim3(256), 0,
                        (hipStream_t)stream, (const __bf16*)feat, pos_emb, tokens, N, H, C, frames_per_sample, mod_off, T,
-                       ds6g_drop_threshold(drop_p), 1.f / (1.f - drop_p), seed, seed_off);
+                       ds6g_drop_threshold(drop_p), 1.f / (1.f - drop_p), seed, seed_off, g_ds6g_salt);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }

@@ -7,6 +7,7 @@
 #include "common.h"
 
 int g_ds6g_bf16 = 0;
+thread_local const uint64_t* g_ds6g_salt = nullptr;
 
 namespace {
 
@@ -43,6 +44,20 @@ __global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ x,
 struct AdamArgs {
     float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, ema_decay, grad_scale;
 };
+// device-resident per-step scalars of the optimizer (ds6g_adamw_state_advance / ds6g_adamw_step_dev): a captured hipGraph of
+// the training step freezes its launch arguments, so what changes from step to step lives in device memory instead
+struct AdamDev {
+    float lr;        // written by the host when the schedule changes it
+    float bc1;       // 1 - beta1^step
+    float bc2_sqrt;  // sqrt(1 - beta2^step)
+    int step;        // 1-based count of steps taken
+};
+__global__ void adamw_advance_kernel(AdamDev* st, float beta1, float beta2) {
+    const int step = st->step + 1;
+    st->step = step;
+    st->bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    st->bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+}
 
 // sum of squares of n4*4 floats: per-block double partials, the LAST block to finish (device-scope counter) adds them in
 // index order (deterministic) and writes out[0] = ||g||_2, out[1] = min(1, max_norm / (||g||_2 + 1e-6)) - the
@@ -88,8 +103,10 @@ __global__ __launch_bounds__(256) void grad_norm_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     float* __restrict__ shadow, long n4, AdamArgs a,
-                                                    const float* __restrict__ grad_scale_dev) {
+                                                    const float* __restrict__ grad_scale_dev,
+                                                    const AdamDev* __restrict__ dev) {
     if (grad_scale_dev) a.grad_scale *= *grad_scale_dev;
+    if (dev) { a.lr = dev->lr; a.bc1 = dev->bc1; a.bc2_sqrt = dev->bc2_sqrt; }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         f32x4 pv = *reinterpret_cast<f32x4*>(p + i * 4);
         const f32x4 gv = a.grad_scale * *reinterpret_cast<const f32x4*>(g + i * 4);
@@ -224,7 +241,33 @@ int ds6g_adamw_step(float* p, const float* g, float* m, float* v, float* shadow,
     const long n4 = n / 4;
     const int grid = (int)(n4 + 255) / 256 < 4096 ? (int)((n4 + 255) / 256) : 4096;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, shadow, n4, a,
-                       grad_scale_dev);
+                       grad_scale_dev, (const AdamDev*)nullptr);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+// state: 16 bytes of device memory {float lr, float bc1, float bc2_sqrt, int step} (zero-initialised; the host writes lr).
+// advance: step += 1 and the bias corrections of that step, computed on the device.
+int ds6g_adamw_state_advance(void* state, float beta1, float beta2, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(state);
+    hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (AdamDev*)state, beta1, beta2);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+// ds6g_adamw_step with lr / bias corrections read from `state` at run time (hipGraph-replayable: no per-step launch argument)
+int ds6g_adamw_step_dev(float* p, const float* g, float* m, float* v, float* shadow, long n, const void* state, float beta1,
+                        float beta2, float eps, float wd, float ema_decay, float grad_scale, const float* grad_scale_dev,
+                        void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(p && g && m && v && state && n % 4 == 0);
+    AdamArgs a;
+    a.lr = 0.f; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd; a.bc1 = 1.f; a.bc2_sqrt = 1.f;
+    a.ema_decay = ema_decay; a.grad_scale = grad_scale;
+    const long n4 = n / 4;
+    const int grid = (int)(n4 + 255) / 256 < 4096 ? (int)((n4 + 255) / 256) : 4096;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, shadow, n4, a, grad_scale_dev,
+                       (const AdamDev*)state);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }
@@ -286,6 +329,13 @@ int ds6g_cast_f32_bf16(const float* src, void* dst, long n, void* stream) {
     const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n4);
     DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+// dev_ptr: one uint64 in device memory (or NULL to switch the mechanism off) added to the dropout counter offset of every
+// launch this thread makes from now on - read by the kernels when they run, not when they are launched
+int ds6g_set_dropout_salt(const uint64_t* dev_ptr) {
+    g_ds6g_salt = dev_ptr;
     return DS6G_OK;
 }
 

@@ -209,7 +209,12 @@ class TransFuser(nn.Module):
         if pretrain_weight:
             self.load_pretrained_weight()
         self._seed = 0x5DEECE66D
-        self._drop_counter = 0
+        self._drop_counter = 0   # counter offset of the next dropout site inside the CURRENT forward (restarts at 0 every forward)
+        # device-resident dropout salt: advanced by SALT_STRIDE on the device at the start of every training forward and
+        # added to every mask counter by the kernels at run time (ds6g_set_dropout_salt), so the launch arguments of a step
+        # are the same every step (hipGraph-replayable) while the masks are fresh; _salt_host mirrors it on the host
+        self._salt = None
+        self._salt_host = 0
         self._ws_main = None
         self._ws_side = {}
         self._side_streams = None
@@ -472,13 +477,31 @@ class TransFuser(nn.Module):
         self._seed = (z ^ (z >> 31)) if rank else int(seed) & 0xFFFFFFFFFFFFFFFF
         return self._seed
 
+    SALT_STRIDE = 1 << 40   # counter space of one forward (bs=32: 4e9 attention-mask elements per step)
+
     def rng_state(self):
-        """(seed, counter) of the dropout stream - saved with the optimizer state so a resumed run continues the mask
+        """(seed, salt) of the dropout stream - saved with the optimizer state so a resumed run continues the mask
         sequence instead of replaying it from step 0."""
-        return dict(seed=int(self._seed), counter=int(self._drop_counter))
+        return dict(seed=int(self._seed), counter=int(self._salt_host))
 
     def set_rng_state(self, st):
-        self._seed, self._drop_counter = int(st["seed"]), int(st["counter"])
+        self._seed, self._salt_host = int(st["seed"]), int(st["counter"])
+        if self._salt is not None:
+            self._salt.fill_(self._salt_host)
+
+    def _advance_salt(self):
+        """start of a training forward: new mask epoch (device add: capturable), counters restart at 0"""
+        if self._salt is None:
+            self._salt = torch.full((1,), self._salt_host, dtype=torch.int64, device=self.device)
+        self._salt.add_(self.SALT_STRIDE)
+        self._salt_host += self.SALT_STRIDE
+        self._drop_counter = 0
+        # this forward's own copy: its backward regenerates the masks from it even if another forward ran in between
+        self._salt_cur = self._salt.clone()
+
+    def _note_replayed_step(self):
+        """a captured training step was replayed: the device advanced the salt, the host mirror follows"""
+        self._salt_host += self.SALT_STRIDE
 
     def _next_drop(self, numel):
         off = self._drop_counter
@@ -901,6 +924,8 @@ class TransFuser(nn.Module):
         assert gps.shape == (B, 2, 2), gps.shape
         if train:
             self._nbt.add_(1)
+            self._advance_salt()
+        L.set_dropout_salt(self._salt_cur.data_ptr() if train else 0)
         trunks = self._trunks()
         feats, stem_ctx = [], []
         streams = self._fork() if self.multi_stream else None
@@ -975,8 +1000,11 @@ class TransFuser(nn.Module):
             gru = (logits, saved)
             logits = pred
         tape = None
+        if not record:
+            L.set_dropout_salt(0)
         if record:
-            tape = (B, stem_ctx, layer_ctx, stage_ctx, (fused, h1, h2, [f.shape for f in feats], gru, feats[0].dtype), gps)
+            tape = (B, stem_ctx, layer_ctx, stage_ctx, (fused, h1, h2, [f.shape for f in feats], gru, feats[0].dtype), gps,
+                    self._salt_cur if train else None)
         return logits, tape
 
     # ================================================================ backward walk =============
@@ -1194,8 +1222,9 @@ class TransFuser(nn.Module):
         L = lib()
         st = ops._stream()
         cfg = self.config
-        B, stem_ctx, layer_ctx, stage_ctx, head, gps = tape
+        B, stem_ctx, layer_ctx, stage_ctx, head, gps, salt = tape
         fused, h1, h2, fshapes, gru, fdtype = head
+        L.set_dropout_salt(salt.data_ptr() if salt is not None else 0)
         self._begin_backward()
         if gru is not None:  # back through the GRU head: dpred (B, pred_len, 64) -> gradient of the join output
             z0, saved = gru
@@ -1259,6 +1288,7 @@ class TransFuser(nn.Module):
             self._milestone_done(2 + 2 * (4 - s))
         self._milestone_done(9)
         self._end_backward()
+        L.set_dropout_salt(0)
 
 
 class TransFuser30to5(TransFuser):

@@ -77,6 +77,9 @@ class FusedAdamW:
         self.max_grad_norm = max_grad_norm
         self._clip_out = torch.zeros(2, dtype=F32, device=model.device)           # [total norm, clip coefficient]
         self._clip_ws = torch.zeros(8 + 8 * 1024, dtype=torch.uint8, device=model.device)
+        # per-step scalars in device memory {lr, bc1, bc2_sqrt, step}: the step is hipGraph-replayable (CapturedTrainStep)
+        self._dev = torch.zeros(4, dtype=F32, device=model.device)
+        self._dev_lr = None
         p, g = model.flat_parameters()
         self.m = torch.zeros_like(p)
         self.v = torch.zeros_like(p)
@@ -99,16 +102,25 @@ class FusedAdamW:
         p, g = self.model.flat_parameters()
         self.step_count += 1
         grp = self.param_groups[0]
+        self.sync_lr()
+        lib().adamw_state_advance(self._dev.data_ptr(), grp["betas"][0], grp["betas"][1], ops._stream())
         coef = 0
         if self.max_grad_norm is not None:
             lib().grad_norm_clip(g.data_ptr(), g.numel(), float(self.max_grad_norm), float(self.grad_scale),
                                  self._clip_out.data_ptr(), self._clip_ws.data_ptr(), self._clip_ws.numel(), ops._stream())
             coef = self._clip_out.data_ptr() + 4
-        lib().adamw_step(p.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                         0 if self.shadow is None else self.shadow.data_ptr(), p.numel(), self.step_count,
-                         float(grp["lr"]), grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"],
-                         0.0 if self.ema_decay is None else float(self.ema_decay), float(self.grad_scale), coef,
-                         ops._stream())
+        lib().adamw_step_dev(p.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                             0 if self.shadow is None else self.shadow.data_ptr(), p.numel(), self._dev.data_ptr(),
+                             grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"],
+                             0.0 if self.ema_decay is None else float(self.ema_decay), float(self.grad_scale), coef,
+                             ops._stream())
+
+    def sync_lr(self):
+        """write the scheduled lr to device memory when it changed (a tiny copy, outside any captured graph)"""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._dev_lr:
+            self._dev[0:1].fill_(lr)
+            self._dev_lr = lr
 
     def last_grad_norm(self):
         """total gradient norm of the last clipped step (host read: synchronises)"""
@@ -122,6 +134,7 @@ class FusedAdamW:
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.step_count = int(sd["step"])
+        self._dev.view(torch.int32)[3:4].fill_(self.step_count)
         if self.shadow is not None and sd.get("shadow") is not None:
             self.shadow.copy_(sd["shadow"])
         if sd.get("dropout_rng") is not None:  # resume the mask sequence, do not replay it from step 0
@@ -312,6 +325,58 @@ def save_pred_to_csv(y_pred, top_k=(1, 2, 3), target_csv="beam_pred.csv"):
         f.write("index," + ",".join(f"top-{k} beam" for k in top_k) + "\n")
         for i, row in enumerate(np.asarray(y_pred)):
             f.write(f"{i}," + ",".join(str(int(row[k - 1]) + 1) for k in top_k) + "\n")
+
+
+class CapturedTrainStep:
+    """One whole training iteration (zero_grad -> forward -> focal loss -> backward -> AdamW [+ EMA]) captured into ONE HIP
+    graph and replayed: ~2000 kernel launches on 5 streams become one host call.  Everything that changes from step to step
+    lives in device memory - the dropout salt (TransFuser._salt, added to every mask counter at run time), the optimizer's
+    step count / bias corrections / lr (FusedAdamW._dev), BatchNorm's num_batches_tracked - so a replay is bit-identical to
+    the eager iteration it stands for.  step(batch) copies a new batch into the graph's static input buffers first.
+    Single process only (the data-parallel all-reduce stays on the eager path)."""
+
+    def __init__(self, model, optimizer, batch, ema=None, warmup=2):
+        if model.grad_ready_hook is not None:
+            raise RuntimeError("CapturedTrainStep: data-parallel training runs eagerly (bucketed all-reduce)")
+        self.model, self.optimizer, self.ema = model, optimizer, ema
+        dev = model.device
+        clone = lambda seq: [t.to(dev, F32).contiguous().clone() for t in seq]  # noqa: E731
+        fronts, lidars, radars, gps, target = batch
+        self.static = (clone(fronts), clone(lidars), clone(radars), gps.to(dev, F32).contiguous().clone(),
+                       target.to(dev, F32).contiguous().clone())
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):   # lazy one-time work (streams, scratch growth, bf16 shadow) outside the capture
+            for _ in range(warmup):
+                train_iteration(model, optimizer, self.static, ema)
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        optimizer.sync_lr()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.logits = train_iteration(model, optimizer, self.static, ema)
+        # a capture records, it does not execute: the device-side counters did not move, so take the host mirrors back
+        optimizer.step_count -= 1
+        model._salt_host -= model.SALT_STRIDE
+        self.steps_replayed = 0
+
+    def step(self, batch=None):
+        if batch is not None:
+            fronts, lidars, radars, gps, target = batch
+            for dst, src in zip(self.static[0] + self.static[1] + self.static[2] + [self.static[3], self.static[4]],
+                                list(fronts) + list(lidars) + list(radars) + [gps, target]):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+        self.optimizer.sync_lr()
+        self.graph.replay()
+        # host mirrors of the device-side counters the graph advanced
+        self.optimizer.step_count += 1
+        self.model._note_replayed_step()
+        self.steps_replayed += 1
+        return self.loss, self.logits
+
+    __call__ = step
 
 
 def train_iteration(model, optimizer, batch, ema=None, reducer=None):

@@ -46,6 +46,12 @@ int ds6g_set_debug_flags(int flags);
 int ds6g_set_compute_mode(int mode);
 int ds6g_get_compute_mode(void);
 
+/* Dropout masks are a pure function of (seed, seed_off + element index).  seed_off is a launch argument, frozen when a
+ * training step is captured into a hipGraph; ds6g_set_dropout_salt(dev_ptr) makes every kernel that draws a mask add the
+ * uint64 at dev_ptr to seed_off when it RUNS (the caller advances that value on the device once per step), so replays draw
+ * fresh masks.  Applies to the launches of the calling thread from now on (thread-local); NULL switches it off. */
+int ds6g_set_dropout_salt(const uint64_t* dev_ptr);
+
 /* ---- igemm.hip : Conv2d / Linear as implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------
  * Conv2d(bias=False) of the ResNet trunks: model2_seq.py:495,500,505 (7x7/2 stems), :510-512,
  * 528-530,546-548,565-567 (BasicBlock 3x3 and 1x1/2 downsample).  C and K multiples of 4. */
@@ -307,6 +313,13 @@ int ds6g_focal_loss(const float* logits, const float* target, float* loss, float
 int ds6g_adamw_step(float* p, const float* g, float* m, float* v, float* shadow, long n, int step, float lr,
                     float beta1, float beta2, float eps, float wd, float ema_decay, float grad_scale,
                     const float* grad_scale_dev, void* stream);
+/* the same step with its per-step scalars in DEVICE memory, so that a hipGraph capture of the whole training step can be
+ * replayed: state = 16 bytes {float lr, float bc1, float bc2_sqrt, int step}, zero-initialised; the host writes lr when the
+ * schedule changes it; ds6g_adamw_state_advance (one thread) increments step and recomputes the bias corrections. */
+int ds6g_adamw_state_advance(void* state, float beta1, float beta2, void* stream);
+int ds6g_adamw_step_dev(float* p, const float* g, float* m, float* v, float* shadow, long n, const void* state, float beta1,
+                        float beta2, float eps, float wd, float ema_decay, float grad_scale, const float* grad_scale_dev,
+                        void* stream);
 /* torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) of the 30->5 training step (train2_seq_30to5.py:120) on
  * the flat gradient arena: out[0] = pre_scale * ||g||_2, out[1] = min(1, max_norm / (out[0] + 1e-6)); the gradients are
  * not rewritten - pass out + 1 to ds6g_adamw_step as grad_scale_dev.  One launch (last-block-done reduction in index

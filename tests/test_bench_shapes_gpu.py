@@ -386,9 +386,9 @@ def _keep_mask(seed, off, shape, p):
 
 def test_dropout_masks_are_plumbed_consistently_at_model_level(dev):
     """Train mode with the reference's dropout 0.1 on all three sites.  The masks are a pure function of (seed, counter):
-    this test re-derives every site's counter offset from the documented order (per stage: embd_drop on (B, T, C); per
-    block: attn_drop on (B, nh, T, T), resid_drop after proj, resid_drop after the MLP; each advanced to the next
-    multiple of 1024), rebuilds the masks on the CPU and runs the ORACLE on them.  Forward logits must match to 1e-3 and
+    this test re-derives every site's counter offset from the documented order (the step's salt, then per stage:
+    embd_drop on (B, T, C); per block: attn_drop on (B, nh, T, T), resid_drop after proj, resid_drop after the MLP; each
+    advanced to the next multiple of 1024), rebuilds the masks on the CPU and runs the ORACLE on them.  Forward logits must match to 1e-3 and
     the gradients (whose backward kernels regenerate the masks from offsets handed over through fused kernels:
     layernorm_bwd's dx_drop, avgpool_tokens_bwd's embd mask, the attention backward) like in the dropout-free test."""
     from oracle import fusion_ref as fr
@@ -398,9 +398,13 @@ def test_dropout_masks_are_plumbed_consistently_at_model_level(dev):
     B = 2
     imgs, lids, rads, gps, target, _ = fr.make_inputs(rcfg, B, seed=117)
     model.train()
-    seed, counter = model._seed, [model._drop_counter]
     loss, logits = model.train_step_loss(imgs, lids, rads, gps, target)
     torch.cuda.synchronize()
+    # effective counter offset of a site = the step's salt (device-resident, advanced once per training forward; the host
+    # mirrors it) + the site's offset inside the forward, which restarts at 0 every step
+    seed, salt = model._seed, model._salt_host
+    assert salt == int(model._salt.item()) == model.SALT_STRIDE
+    counter = [salt]
 
     def mask_fn(shape, p):
         n = int(np.prod(shape))
@@ -412,7 +416,7 @@ def test_dropout_masks_are_plumbed_consistently_at_model_level(dev):
     sdo = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not fr.is_buffer(k)) else v.clone())
            for k, v in sd.items()}
     ologits = fr.transfuser_forward(sdo, imgs, lids, rads, gps, rcfg, fr.Ctx(training=True, dropout=True, mask_fn=mask_fn))
-    assert counter[0] == model._drop_counter      # the oracle visited exactly the sites the HIP walk counted
+    assert counter[0] - salt == model._drop_counter      # the oracle visited exactly the sites the HIP walk counted
     oloss = tr.sigmoid_focal_loss(ologits, target)
     oloss.backward()
     assert rel(logits, ologits.detach()) < TOL

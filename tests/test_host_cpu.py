@@ -195,11 +195,11 @@ def test_dropout_seed_differs_per_rank_and_rng_state_roundtrips():
     seeds = [m.set_dropout_seed(base, r) for r in range(8)]
     assert seeds[0] == base and len(set(seeds)) == 8 and all(0 <= s < 2 ** 64 for s in seeds)
     m.set_dropout_seed(base, 3)
-    m._drop_counter = 12345 * 1024
+    m._salt_host = 12345 * m.SALT_STRIDE          # 12345 training forwards taken
     st = m.rng_state()
     m2 = TransFuser(GlobalConfig(n_layer=1), "cpu")
     m2.set_rng_state(st)
-    assert (m2._seed, m2._drop_counter) == (seeds[3], 12345 * 1024)
+    assert (m2._seed, m2._salt_host) == (seeds[3], 12345 * m.SALT_STRIDE)
 
 
 def test_per_scenario_metrics_and_confidence_csv(tmp_path):

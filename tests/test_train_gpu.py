@@ -151,3 +151,59 @@ def test_training_trajectory_tracks_cpu_oracle(dev):
     err = ((got - want).abs().max() / want.abs().max()).item()
     print(f"trajectory: eval logits after 4 steps differ by {err:.2e} (relative to the largest logit)")
     assert err < 5e-2, err
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_captured_train_step_is_bit_identical_to_eager(dev, mode):
+    """CapturedTrainStep: the whole iteration (forward, focal loss, backward, AdamW + EMA; dropout 0.1; three trunk streams
+    and the weight-gradient companion stream) replayed from ONE HIP graph must leave the same parameters, optimizer state,
+    BatchNorm buffers and loss as the eager iterations, bit for bit - including fresh dropout masks on every replay (the
+    salt lives in device memory) and the bias corrections of the right step (optimizer scalars in device memory)."""
+    from deepsense6g_tii_amd import ops
+    from deepsense6g_tii_amd.model import GlobalConfig, TransFuser
+    from deepsense6g_tii_amd.train import EMA, CapturedTrainStep, FusedAdamW, train_iteration
+    from oracle import fusion_ref as fr
+    kw = dict(n_layer=2)        # reference dropout 0.1 / 0.1 / 0.1
+    rcfg = fr.RefConfig(**kw)
+    sd = fr.make_state(rcfg, seed=8)
+    batches = [fr.make_inputs(rcfg, 2, seed=60 + i)[:5] for i in range(3)]
+    ops.set_compute_mode(mode)
+    try:
+        runs = []
+        for captured in (False, True):
+            model = TransFuser(GlobalConfig(**kw), dev)
+            model.load_state_dict(sd)
+            model.train()
+            opt = FusedAdamW(model, lr=1e-3, ema_decay=0.999)
+            ema = EMA(model, 0.999, opt)
+            ema.register()
+            losses = []
+            if captured:
+                # the capture runs 2 eager warm-up iterations on batches[0] (the capture pass itself executes nothing): the
+                # other run mirrors them eagerly
+                step = CapturedTrainStep(model, opt, batches[0], ema, warmup=2)
+                for b in batches[1:]:
+                    opt.param_groups[0]["lr"] *= 0.5          # a schedule change between replays reaches the graph
+                    loss, _ = step(b)
+                    losses.append(float(loss))
+                assert step.steps_replayed == 2
+            else:
+                for _ in range(2):
+                    train_iteration(model, opt, batches[0], ema)
+                for b in batches[1:]:
+                    opt.param_groups[0]["lr"] *= 0.5
+                    loss, _ = train_iteration(model, opt, b, ema)
+                    losses.append(float(loss))
+            torch.cuda.synchronize()
+            runs.append(dict(p=model.flat_parameters()[0].clone(), m=opt.m.clone(), v=opt.v.clone(), sh=opt.shadow.clone(),
+                             bufs=[b.clone() for b in model.buffers()], losses=losses, steps=opt.step_count,
+                             salt=(model._salt_host, int(model._salt.item()))))
+        a, b = runs
+        assert a["losses"] == b["losses"] and a["steps"] == b["steps"] == 4
+        assert a["salt"] == b["salt"] and a["salt"][0] == a["salt"][1]
+        for k in ("p", "m", "v", "sh"):
+            assert torch.equal(a[k], b[k]), k
+        for x, y in zip(a["bufs"], b["bufs"]):
+            assert torch.equal(x, y)
+    finally:
+        ops.set_compute_mode("f32")
