@@ -224,8 +224,8 @@ def main():
     ap.add_argument("--image-only", action="store_true",
                     help="BASELINE configs[1]: zeroed LiDAR / radar inputs - the reference's own 'zerolike' missing-modality "
                          "semantics (mambafuser_seq.py:384-391); same kernels and FLOPs, other input statistics")
-    ap.add_argument("--graph", type=int, default=1,
-                    help="1 (default, single process): the timed steps replay ONE captured HIP graph of the whole iteration "
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1 (single process): the timed steps replay ONE captured HIP graph of the whole iteration "
                          "(train.CapturedTrainStep, bit-identical to the eager iteration); 0: eager launches.  Data-parallel "
                          "runs (--gpus > 1) are always eager (bucketed all-reduce issued from the backward walk)")
     ap.add_argument("--single-stream", action="store_true",
