@@ -22,6 +22,7 @@
 // Only the wave-uniform k walk of igemm.hip exists here (channel counts multiples of 64; wgrad: see bgemm_wgrad_walk):
 // every layer of the model but the 4-channel stems qualifies, and the stems keep the fp32-storage kernel.
 #include "common.h"
+#include <cstdlib>
 
 void* ds6g_prof_open(int variant, double flops, hipStream_t st);
 void ds6g_prof_close(void* rec, hipStream_t st);
@@ -477,7 +478,22 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
 }
 
 // ------------------------------------------------------------------------------------------------
-int g_bg_min_blocks = 512;  // 128 x 128 tiles once they still give this many workgroups, else 64 x 64
+// 128 x 128 tiles once they give this many workgroups, else 64 x 64 (tools/bench_bgemm.py with DS6G_BG_TILE forced: the large
+// tile wins from ~240 workgroups up - 32x32 x 128 ch and 16x16 x 256 ch convs at N = 60 633-677 vs 536-562 TFLOP/s, stage-4 GPT
+// linears +15-20 % - and loses on the 64-wide and the 8x8 x 512 layers, 120 workgroups)
+int g_bg_min_blocks = 200;
+// wgrad split-K: workgroups aimed at (measured sweep 128 .. 4096, tools/bench_bgemm.py with DS6G_BG_WTARGET: few, long splits
+// win - convs peak at ~384, the GPT linears at ~512; 1024 costs 15-25 %, 2048+ up to 2x through the slab reduction)
+int g_bg_wgrad_target = 0;
+int g_bg_force_tile = -1;   // tuning experiments (env DS6G_BG_TILE / DS6G_BG_MINBLOCKS, read once)
+void bg_env() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    if (const char* e = getenv("DS6G_BG_TILE")) g_bg_force_tile = atoi(e);
+    if (const char* e = getenv("DS6G_BG_MINBLOCKS")) g_bg_min_blocks = atoi(e);
+    if (const char* e = getenv("DS6G_BG_WTARGET")) g_bg_wgrad_target = atoi(e);
+}
 
 void fill_conv(BgemmParams& p, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
     p = BgemmParams{};
@@ -527,6 +543,8 @@ int launch_bgemm(BgemmParams& p, int out16, int splits, int tile, hipStream_t st
 }
 
 int pick_tile(int Mg, int Ng, long splits) {
+    bg_env();
+    if (g_bg_force_tile >= 0) return g_bg_force_tile;
     return ((long)cdiv(Mg, 128) * cdiv(Ng, 128) * splits >= g_bg_min_blocks && Mg > 64 && Ng > 64) ? 0 : 1;
 }
 
@@ -536,7 +554,9 @@ int run_wgrad(BgemmParams& p, float* dw, int accumulate, float* dbias, float* ws
     const long slab_elems = out_elems + (dbias ? p.Mg : 0);
     const int tile = (p.Mg >= 128 && p.Ng >= 128) ? 0 : 1;
     const long tiles = (long)cdiv(p.Mg, tile == 0 ? 128 : 64) * cdiv(p.Ng, tile == 0 ? 128 : 64);
-    long splits = (1024 + tiles - 1) / tiles;
+    bg_env();
+    const long target = g_bg_wgrad_target > 0 ? g_bg_wgrad_target : (p.N * p.Ho == 1 ? 512 : 384);
+    long splits = (target + tiles - 1) / tiles;
     const long max_by_k = (p.Kg + 4 * BK - 1) / (4 * BK);   // >= 4 k-tiles per split
     if (splits > max_by_k) splits = max_by_k;
     const long max_by_ws = (long)(ws_bytes / (slab_elems * sizeof(float)));

@@ -21,6 +21,7 @@
 // image: whole 256/512-B rows per wave-instruction and 8 conflict-free ds_read_b32 per fragment.
 #include "common.h"
 #include <vector>
+#include <cstdlib>
 
 extern int g_ds6g_attn_percu;  // attention.hip: split-heuristic override (timing experiments)
 extern int g_ds6g_attn_handover;
@@ -66,6 +67,8 @@ struct IgemmParams {
     int wg_rows;         // FAST WGRAD: 0 = a k-tile of 16 pixels stays inside one output row; else rows per k-tile (16 / Wo)
     int is_linear;       // host-side only: the problem is a Linear layer (split-K heuristics)
     int want_colsum;     // WGRAD: also emit column sums of the A operand (bias gradient) behind each slab
+    int xcd_splits;      // WGRAD: map (tile, split) so that the column tiles of ONE split run on one XCD (they read the same
+                         // dy rows and overlapping x rows: few output tiles x many splits, i.e. the 64-channel 3x3 layers)
     // DGRAD of a strided conv is run per input-pixel parity class: pixels h = h0 + hstep*hh (hh < Hs), taps
     // r = r0 + rstep*ri (ri < nr) - only the taps that hit a real output pixel, no structural zeros
     int h0, hstep, Hs, w0, wstep, Ws, r0, rstep, nr, s0, sstep, ns;
@@ -138,8 +141,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams pin) {
     // XCD-aware tile order: hardware deals consecutive workgroups round-robin over the 8 XCDs (each
     // with a private L2); remap so that every XCD walks a contiguous run of tiles (tile_n fastest),
     // i.e. tiles sharing A rows / neighbouring image rows hit the same L2.  Bijective for any grid.
-    int wg;
-    {
+    int wg, split = blockIdx.z;
+    if (MODE == MODE_WGRAD && p.xcd_splits) {
+        // the hardware deals workgroups to XCDs in dispatch order (x fastest, then z): give every XCD a contiguous run of
+        // (split, tile) pairs, tile fastest, so the tiles of a split - same dy rows, overlapping x rows - share one L2
+        const int nwg = gridDim.x * gridDim.z, orig = blockIdx.x + gridDim.x * blockIdx.z;
+        const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        split = lin / (int)gridDim.x;
+        wg = lin - split * (int)gridDim.x;
+    } else {
         const int nwg = gridDim.x, orig = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
@@ -147,7 +158,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams pin) {
     const int tile_m = wg / p.tiles_n;
     const int tile_n = wg - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int split = blockIdx.z;
     const int kbegin = (MODE == MODE_WGRAD) ? split * p.k_per_split : 0;
     const int kend = (MODE == MODE_WGRAD) ? min(p.Kg, kbegin + p.k_per_split) : p.Kg;
     const int nk = (kend - kbegin + BK - 1) / BK;
@@ -848,6 +858,11 @@ int run_wgrad(IgemmParams& p, float* dw, int accumulate, float* dbias, int accum
     p.k_per_split = kps;
     p.split_stride = (size_t)slab_elems;
     p.want_colsum = dbias != nullptr;
+    {
+        static int xcd_mode = -1;   // env DS6G_WGRAD_XCD: 0 off, 1 (default) few-tile convs, 2 every conv wgrad (experiment)
+        if (xcd_mode < 0) { const char* e = getenv("DS6G_WGRAD_XCD"); xcd_mode = e ? atoi(e) : 1; }
+        p.xcd_splits = (!p.is_linear && splits >= 8 && ((xcd_mode == 1 && tiles <= 12) || xcd_mode == 2)) ? 1 : 0;
+    }
     if (splits == 1 && !accumulate && !dbias) {
         p.out = dw;
         return launch_igemm<MODE_WGRAD>(p, 1, tile, st);
