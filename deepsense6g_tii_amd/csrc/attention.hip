@@ -59,6 +59,7 @@ struct AttnParams {
     // split slabs and every kernel-internal tensor stay fp32); o16: the backward reads its forward output as bf16
     int out16;
     int o16;
+    int in16;   // q / k / v / d_o are bf16 in HBM (kernels instantiated with BF == 4)
 };
 
 __device__ __forceinline__ int krow16(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -127,6 +128,73 @@ __device__ __forceinline__ float dim_read(unsigned tile, const unsigned* dtab, i
     return *reinterpret_cast<lds_cf*>(tile + dtab[k] + (unsigned)cst);
 }
 
+// ---- bf16-STORED tiles (template value BF == 4: q / k / v / dO live in HBM as bf16; implies the bf16 matrix cores) -------
+// LDS image [32 rows][HD] bf16, row = HD*2 bytes, filled by LDS-DMA; the 16-B chunk index (8 dims) is XOR-swizzled by the
+// row so that BOTH read patterns are conflict-free: "row on the lane" (one ds_read_b128 = the MFMA operand of a 16-deep
+// k-step as it lies in memory) and "dim on the lane" (ds_read_b64_tr_b16: 4 rows x 16 dims per 16-lane group, delivered
+// transposed - two of them per k-step and 32-dim block).  HD = 128 uses the XOR the CDNA guide gives for 256-byte rows.
+template <int HD>
+__device__ __forceinline__ int swz16(int r) {
+    if (HD >= 128) return ((r & 3) << 2) | ((r >> 2) & 3);
+    if (HD == 64) return (((r >> 1) & 1) << 2) | ((r >> 2) & 3);
+    if (HD == 32) return (r >> 2) & 3;
+    return (r >> 3) & 1;
+}
+// base_off / ld in ELEMENTS; one wave-instruction = 1 KiB = 512 / HD rows
+template <int HD>
+__device__ __forceinline__ void tile_dma16(const i32x4 srd, const float* lds_tile, unsigned base_off, int row0, int T,
+                                           int ld, int wave, int lane) {
+    constexpr int NC8 = HD / 8;
+    constexpr int NWI = HD / 16;  // wave-instructions per 32-row tile
+#pragma unroll
+    for (int j = 0; j < (NWI + 3) / 4; ++j) {
+        const int wi = wave + 4 * j;
+        if (wi < NWI) {
+            const int g = wi * 64 + lane;
+            const int row = g / NC8, pos = g % NC8;
+            const int c = pos ^ swz16<HD>(row);
+            const unsigned off = base_off + (unsigned)(row0 + row) * (unsigned)ld + (unsigned)(c * 8);
+            dma16(srd, lds_addr(lds_tile) + (unsigned)wi * 1024u, (row0 + row) < T ? off * 2u : OOB_OFF);
+        }
+    }
+}
+typedef __attribute__((address_space(3))) const bf16x8 lds_cb8;
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+template <int HD>
+__device__ __forceinline__ bf16x8 row_read16(unsigned tile, int r, int c) {
+    return *reinterpret_cast<lds_cb8*>(tile + (unsigned)(r * HD * 2 + ((c ^ swz16<HD>(r)) << 4)));
+}
+// operand fragment of k-step s2 for "dim on the lane": element e <-> row krow16(8 s2 + e, half), dim 32 blk + (lane & 31)
+template <int HD>
+__device__ __forceinline__ bf16x8 dim_read16(unsigned tile, int s2, int blk, int lane) {
+    const int half = lane >> 5, g = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
+    int dim0 = blk * 32 + 16 * g + 4 * pp;
+    if (HD < 32 && dim0 >= HD) dim0 -= 16;  // HD = 16: lanes 16..31 re-read valid dims (their outputs are never stored)
+    bf16x4v part[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int row = 16 * s2 + 8 * t + 4 * half + q;
+        const unsigned a = tile + (unsigned)(row * HD * 2 + (((dim0 >> 3) ^ swz16<HD>(row)) << 4) + (dim0 & 7) * 2);
+        part[t] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4v*)(unsigned long)a);
+    }
+    return __builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// the lane's half row (dims half*HD/2 ..) as packed bf16 in the first HD/4 floats of reg (raw bits; no scaling possible)
+template <int HD>
+__device__ __forceinline__ void load_frag16(float* reg, const float* base, long row_off, int half) {
+    const __bf16* b16 = reinterpret_cast<const __bf16*>(base);
+#pragma unroll
+    for (int j = 0; j < HD / 16; ++j) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(b16 + row_off + half * (HD / 2) + 8 * j);
+        reg[4 * j] = v[0]; reg[4 * j + 1] = v[1]; reg[4 * j + 2] = v[2]; reg[4 * j + 3] = v[3];
+    }
+}
+template <int HD, int BF>
+__device__ __forceinline__ void tile_dma_any(const i32x4 srd, const float* lds_tile, unsigned base_off, int row0, int T, int ld,
+                                             int wave, int lane);
+template <int HD, int BF>
+__device__ __forceinline__ void load_frag_any(float* reg, const float* base, long row_off, int half, float mul);
+
 // per-lane operand fragment of row `row` for the transposed products: element ss <-> dim half*HD/2 + ss
 template <int HD>
 __device__ __forceinline__ void load_frag(float* reg, const float* base, long row_off, int half, float mul) {
@@ -137,10 +205,39 @@ __device__ __forceinline__ void load_frag(float* reg, const float* base, long ro
     }
 }
 
+template <int HD, int BF>
+__device__ __forceinline__ void tile_dma_any(const i32x4 srd, const float* lds_tile, unsigned base_off, int row0, int T, int ld,
+                                             int wave, int lane) {
+    if (BF == 4) tile_dma16<HD>(srd, lds_tile, base_off, row0, T, ld, wave, lane);
+    else tile_dma<HD>(srd, lds_tile, base_off, row0, T, ld, wave, lane);
+}
+// bf16 storage: the fragment stays packed bf16 and is NOT scaled (callers scale the product instead; mul 0 = zero it)
+template <int HD, int BF>
+__device__ __forceinline__ void load_frag_any(float* reg, const float* base, long row_off, int half, float mul) {
+    if (BF == 4) {
+        load_frag16<HD>(reg, base, row_off, half);
+        if (mul == 0.f) {
+#pragma unroll
+            for (int j = 0; j < HD / 4; ++j) reg[j] = 0.f;
+        }
+    } else {
+        load_frag<HD>(reg, base, row_off, half, mul);
+    }
+}
+
 // acc += A . B^T over the head dim: A rows come from the LDS tile (row = lane&31), B from registers
 template <int HD, int BF>
 __device__ __forceinline__ void mma_rows(f32x16& acc, unsigned tile, const float* breg, int l31, int half) {
     constexpr int NCH = HD / 8;  // 16-B chunks per lane half
+    if (BF == 4) {  // bf16-stored: LDS chunk and register chunk ARE the operands (lane half h: dims h*HD/2 + 8c .. + 7)
+#pragma unroll
+        for (int c = 0; c < HD / 16; ++c) {
+            const bf16x8 a8 = row_read16<HD>(tile, l31, half * (HD / 16) + c);
+            const bf16x8 b8 = __builtin_bit_cast(bf16x8, f32x4{breg[4 * c], breg[4 * c + 1], breg[4 * c + 2], breg[4 * c + 3]});
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc, 0, 0, 0);
+        }
+        return;
+    }
     if (BF) {  // bf16 matrix cores: 16 head dims per MFMA (lane half h supplies dims h*HD/2 + 8c .. +7 of chunk c)
 #pragma unroll
         for (int c = 0; c < HD / 16; ++c) {
@@ -189,6 +286,19 @@ __device__ __forceinline__ void mma_rows(f32x16& acc, unsigned tile, const float
 template <int HD, int BF>
 __device__ __forceinline__ void mma_dims(f32x16* acc, unsigned tile, const f32x16& p, const unsigned* dtab) {
     constexpr int NB = (HD + 31) / 32;
+    if (BF == 4) {  // bf16-stored tile: the A fragment comes transposed out of LDS (ds_read_b64_tr_b16), no conversion
+        const int lane_ = (int)(threadIdx.x & 63);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 b8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b8[e] = (__bf16)p[8 * s2 + e];
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dim_read16<HD>(tile, s2, blk, lane_), b8, acc[blk], 0, 0, 0);
+        }
+        return;
+    }
     if (BF) {  // accumulator registers 8s..8s+7 are exactly the bf16 operand fragment of k-step s (key order krow16)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -329,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const i32x4 k_srd = make_srd(p.k, p.bytes_q), v_srd = make_srd(p.v, p.bytes_q);
 
     float qreg[HD / 2];
-    load_frag<HD>(qreg, p.q, head_offq + (long)(q_row < T ? q_row : T - 1) * p.ldq, half, p.scale);
+    load_frag_any<HD, BF>(qreg, p.q, head_offq + (long)(q_row < T ? q_row : T - 1) * p.ldq, half, p.scale);
     f32x16 oacc[NB];
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk)
@@ -340,14 +450,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 
     auto step = [&](const float* Kcp, const float* Vcp, const float* Kn, const float* Vn, int kt, bool more) {
         if (more) {
-            tile_dma<HD>(k_srd, Kn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
-            tile_dma<HD>(v_srd, Vn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
+            tile_dma_any<HD, BF>(k_srd, Kn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
+            tile_dma_any<HD, BF>(v_srd, Vn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
         }
         const unsigned Kc = opaque_tile(Kcp), Vc = opaque_tile(Vcp);
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         mma_rows<HD, BF>(s, Kc, qreg, l31, half);
+        if (BF == 4) {  // the bf16-stored q fragment is unscaled: scale the scores (exact in fp32)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] *= p.scale;
+        }
         const int key0 = kt * 32;
 #ifndef ATTN_ABLATE_SOFTMAX
         float mloc = -INFINITY;
@@ -388,8 +502,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     };
 
     if (t_begin < t_end) {
-        tile_dma<HD>(k_srd, Xa0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
-        tile_dma<HD>(v_srd, Xb0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
+        tile_dma_any<HD, BF>(k_srd, Xa0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
+        tile_dma_any<HD, BF>(v_srd, Xb0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -483,8 +597,8 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
 
     auto step = [&](const float* Kcp, const float* Vcp, const float* Kn, const float* Vn, int kt, bool more) {
         if (more) {
-            tile_dma<HD>(k_srd, Kn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
-            tile_dma<HD>(v_srd, Vn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
+            tile_dma_any<HD, BF>(k_srd, Kn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
+            tile_dma_any<HD, BF>(v_srd, Vn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
         }
         const unsigned Kc = opaque_tile(Kcp), Vc = opaque_tile(Vcp);
         f32x16 s, dp;
@@ -508,8 +622,8 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
     };
 
     if (t_begin < t_end) {
-        tile_dma<HD>(k_srd, Xa0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
-        tile_dma<HD>(v_srd, Xb0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
+        tile_dma_any<HD, BF>(k_srd, Xa0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
+        tile_dma_any<HD, BF>(v_srd, Xb0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -543,8 +657,8 @@ __global__ __launch_bounds__(256, (HD <= 32 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
     float kreg[HD / 2], vreg[HD / 2];
     {
         const long ro = head_offq + (long)(key_ok ? key : T - 1) * p.ldq;
-        load_frag<HD>(kreg, p.k, ro, half, 1.f);
-        if (DO_DK) load_frag<HD>(vreg, p.v, ro, half, 1.f);
+        load_frag_any<HD, BF>(kreg, p.k, ro, half, 1.f);
+        if (DO_DK) load_frag_any<HD, BF>(vreg, p.v, ro, half, 1.f);
     }
     f32x16 dk[NB], dv[NB];
 #pragma unroll
@@ -562,8 +676,8 @@ __global__ __launch_bounds__(256, (HD <= 32 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
     };
     auto step = [&](const float* Qcp, const float* Ocp, const float* Qn, const float* On, int qt, int buf, bool more) {
         if (more) {
-            tile_dma<HD>(q_srd, Qn, (unsigned)head_offq, (qt + 1) * 32, T, p.ldq, wave, lane);
-            tile_dma<HD>(do_srd, On, (unsigned)head_off, (qt + 1) * 32, T, p.ld, wave, lane);
+            tile_dma_any<HD, BF>(q_srd, Qn, (unsigned)head_offq, (qt + 1) * 32, T, p.ldq, wave, lane);
+            tile_dma_any<HD, BF>(do_srd, On, (unsigned)head_off, (qt + 1) * 32, T, p.ld, wave, lane);
             stats(qt + 1, buf ^ 1);
         }
         const unsigned Qc = opaque_tile(Qcp), Oc = opaque_tile(Ocp);
@@ -617,8 +731,8 @@ __global__ __launch_bounds__(256, (HD <= 32 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
     };
 
     if (t_begin < t_end) {
-        tile_dma<HD>(q_srd, Xa0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
-        tile_dma<HD>(do_srd, Xb0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
+        tile_dma_any<HD, BF>(q_srd, Xa0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
+        tile_dma_any<HD, BF>(do_srd, Xb0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
         stats(t_begin, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -650,7 +764,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
     const float* a = o + row * ld + h * hd;
     const float* g = d_o + row * ld + h * hd;
     float acc = 0.f;
-    if (o16) {
+    if (o16 == 3) {       // o and dO both bf16
+        typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+        const __bf16* a16 = reinterpret_cast<const __bf16*>(o) + row * ld + h * hd;
+        const __bf16* g16 = reinterpret_cast<const __bf16*>(d_o) + row * ld + h * hd;
+        for (int d = 0; d < hd; d += 4) {
+            const bf16x4_ x = *reinterpret_cast<const bf16x4_*>(a16 + d), y = *reinterpret_cast<const bf16x4_*>(g16 + d);
+            acc += (float)x[0] * (float)y[0] + (float)x[1] * (float)y[1] + (float)x[2] * (float)y[2] + (float)x[3] * (float)y[3];
+        }
+    } else if (o16) {
         typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
         const __bf16* a16 = reinterpret_cast<const __bf16*>(o) + row * ld + h * hd;
         for (int d = 0; d < hd; d += 4) {
@@ -697,7 +819,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const AttnParams p
     float* tw = Tr[wave];
     auto step = [&](const float* Kcp, const float* Kn, int kt, bool more) {
         if (more) {
-            tile_dma<HD>(k_srd, Kn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
+            tile_dma_any<HD, BF>(k_srd, Kn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
             fetch(fn, kt + 1);
         }
         const unsigned Kc = opaque_tile(Kcp);
@@ -718,7 +840,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const AttnParams p
         }
     };
     if (t_begin < t_end) {
-        tile_dma<HD>(k_srd, Xa0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
+        tile_dma_any<HD, BF>(k_srd, Xa0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
         fetch(f, t_begin);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -758,7 +880,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dv2_kernel(const AttnParams p
     };
     auto step = [&](const float* Ocp, const float* On, int qt, bool more) {
         if (more) {
-            tile_dma<HD>(do_srd, On, (unsigned)head_off, (qt + 1) * 32, T, p.ld, wave, lane);
+            tile_dma_any<HD, BF>(do_srd, On, (unsigned)head_off, (qt + 1) * 32, T, p.ld, wave, lane);
             fetch(sn, qt + 1);
         }
         const unsigned Oc = opaque_tile(Ocp);
@@ -769,7 +891,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dv2_kernel(const AttnParams p
         if (more) s = sn;
     };
     if (t_begin < t_end) {
-        tile_dma<HD>(do_srd, Xb0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
+        tile_dma_any<HD, BF>(do_srd, Xb0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
         fetch(s, t_begin);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -858,8 +980,39 @@ int launch_hd_bf(const AttnParams& p, int hd, dim3 grid, hipStream_t st) {
     return DS6G_OK;
 }
 
+// bf16-stored q / k / v / dO (BF == 4): forward, dK/dV with hand-over, dV from P (HD = 128), dQ from dS
+template <int KIND>
+int launch_hd_st(const AttnParams& p, int hd, dim3 grid, hipStream_t st) {
+#define ATTN_CASE16(HDV)                                                                                      \
+    case HDV:                                                                                                 \
+        if constexpr (KIND == 0) hipLaunchKernelGGL((attn_fwd_kernel<HDV, 4>), grid, dim3(256), 0, st, p);    \
+        if constexpr (KIND == 3) {                                                                            \
+            if constexpr (HDV >= 128) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 2, 4, 1>), grid, dim3(256), 0, st, p); \
+            else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 0, 4, 1>), grid, dim3(256), 0, st, p);          \
+        }                                                                                                     \
+        if constexpr (KIND == 4 && HDV >= 128) hipLaunchKernelGGL((attn_bwd_dv2_kernel<HDV, 4>), grid, dim3(256), 0, st, p); \
+        if constexpr (KIND == 5) hipLaunchKernelGGL((attn_bwd_dq2_kernel<HDV, 4>), grid, dim3(256), 0, st, p); \
+        break;
+    switch (hd) {
+        ATTN_CASE16(16)
+        ATTN_CASE16(32)
+        ATTN_CASE16(64)
+        ATTN_CASE16(128)
+        default:
+            fprintf(stderr, "[ds6g] attention head dim %d not supported (16/32/64/128)\n", hd);
+            return DS6G_ERR_ARG;
+    }
+#undef ATTN_CASE16
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
 template <int KIND>
 int launch_hd(const AttnParams& p, int hd, dim3 grid, hipStream_t st) {
+    if (p.in16) {
+        if constexpr (KIND == 0 || KIND == 3 || KIND == 4 || KIND == 5) return launch_hd_st<KIND>(p, hd, grid, st);
+        else return DS6G_ERR_ARG;
+    }
     if (g_ds6g_bf16 == 3) return launch_hd_bf<KIND, 3>(p, hd, grid, st);
     if (g_ds6g_bf16 == 2) return launch_hd_bf<KIND, 2>(p, hd, grid, st);
     return g_ds6g_bf16 ? launch_hd_bf<KIND, 1>(p, hd, grid, st) : launch_hd_bf<KIND, 0>(p, hd, grid, st);
@@ -882,7 +1035,7 @@ size_t ds6g_attention_workspace_bytes(int B, int T, int nh, int hd, int ld) {
 }
 
 // o = dropout(softmax(q k^T / sqrt(hd))) v ; lse[b][h][t] = logsumexp of the scaled scores
-static int attention_fwd_impl(const float* q, const float* k, const float* v, float* o, int out16, float* lse, int B, int T,
+static int attention_fwd_impl(const float* q, const float* k, const float* v, int in16, float* o, int out16, float* lse, int B, int T,
                               int nh, int hd, int ld_qkv, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
                               size_t ws_bytes, void* stream) {
     DS6G_ENTER();
@@ -894,8 +1047,10 @@ static int attention_fwd_impl(const float* q, const float* k, const float* v, fl
     hipStream_t st = (hipStream_t)stream;
     AttnParams p{};
     p.q = q; p.k = k; p.v = v; p.lse = lse; p.T = T; p.nh = nh; p.B = B; p.ld = ld; p.ldq = ld_qkv; p.ldd = ld;
-    p.bytes = (unsigned)(slab * sizeof(float)); p.slab = slab;
-    p.bytes_q = (unsigned)((((size_t)B * T - 1) * ld_qkv + nh * hd) * sizeof(float));
+    const size_t esz = in16 ? 2 : 4;
+    p.in16 = in16;
+    p.bytes = (unsigned)(slab * esz); p.slab = slab;
+    p.bytes_q = (unsigned)((((size_t)B * T - 1) * ld_qkv + nh * hd) * esz);
     p.scale = 1.0f / sqrtf((float)hd);
     p.thr = ds6g_drop_threshold(drop_p); p.dscale = 1.f / (1.f - drop_p); p.seed = seed; p.seed_off = seed_off; p.salt = g_ds6g_salt;
     const int ntiles = cdiv(T, 32);
@@ -923,18 +1078,27 @@ static int attention_fwd_impl(const float* q, const float* k, const float* v, fl
 int ds6g_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int T, int nh,
                        int hd, int ld_qkv, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
                        size_t ws_bytes, void* stream) {
-    return attention_fwd_impl(q, k, v, o, 0, lse, B, T, nh, hd, ld_qkv, ld, drop_p, seed, seed_off, ws, ws_bytes, stream);
+    return attention_fwd_impl(q, k, v, 0, o, 0, lse, B, T, nh, hd, ld_qkv, ld, drop_p, seed, seed_off, ws, ws_bytes, stream);
 }
 // bf16-storage path: q / k / v fp32 (column blocks of the fused projection output), o written as bf16 [B*T][ld]
 int ds6g_attention_fwd_bf16out(const float* q, const float* k, const float* v, void* o, float* lse, int B, int T, int nh,
                                int hd, int ld_qkv, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
                                size_t ws_bytes, void* stream) {
-    return attention_fwd_impl(q, k, v, (float*)o, 1, lse, B, T, nh, hd, ld_qkv, ld, drop_p, seed, seed_off, ws, ws_bytes,
+    return attention_fwd_impl(q, k, v, 0, (float*)o, 1, lse, B, T, nh, hd, ld_qkv, ld, drop_p, seed, seed_off, ws, ws_bytes,
                               stream);
+}
+// bf16-storage path, all operands bf16 in HBM: q / k / v [B*T][ld_qkv] and o [B*T][ld] bf16 (tiles reach the bf16 MFMA
+// unconverted: bf16 LDS images, transposed LDS reads for the P.V product); lse and the split scratch fp32
+int ds6g_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, float* lse, int B, int T, int nh, int hd,
+                            int ld_qkv, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws, size_t ws_bytes,
+                            void* stream) {
+    DS6G_CHECK_ARG(ld_qkv % 8 == 0 && ld % 8 == 0);
+    return attention_fwd_impl((const float*)q, (const float*)k, (const float*)v, 1, (float*)o, 1, lse, B, T, nh, hd, ld_qkv, ld,
+                              drop_p, seed, seed_off, ws, ws_bytes, stream);
 }
 
 // gradients of the above; delta is a [B][nh][T] scratch (rowsum(dO*O)), written then read
-static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, int o16, const float* d_o,
+static int attention_bwd_impl(const float* q, const float* k, const float* v, int in16, const float* o, int o16, const float* d_o,
                               const float* lse, float* delta, float* dq, float* dk, float* dv, int out16, int B, int T,
                               int nh, int hd, int ld_qkv, int ld, int ld_dqkv, float drop_p, uint64_t seed,
                               uint64_t seed_off, void* ws, size_t ws_bytes, void* stream) {
@@ -948,9 +1112,10 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
     AttnParams p{};
     p.q = q; p.k = k; p.v = v; p.o = const_cast<float*>(o); p.lse = const_cast<float*>(lse); p.d_o = d_o;
     p.delta = delta; p.T = T; p.nh = nh; p.B = B; p.ld = ld; p.ldq = ld_qkv; p.ldd = ld_dqkv;
-    p.out16 = out16; p.o16 = o16;
-    p.bytes = (unsigned)(slab * sizeof(float)); p.slab = slab;
-    p.bytes_q = (unsigned)((((size_t)B * T - 1) * ld_qkv + nh * hd) * sizeof(float));
+    p.out16 = out16; p.o16 = o16; p.in16 = in16;
+    const size_t esz = in16 ? 2 : 4;
+    p.bytes = (unsigned)(slab * esz); p.slab = slab;
+    p.bytes_q = (unsigned)((((size_t)B * T - 1) * ld_qkv + nh * hd) * esz);
     p.scale = 1.0f / sqrtf((float)hd);
     p.thr = ds6g_drop_threshold(drop_p); p.dscale = 1.f / (1.f - drop_p); p.seed = seed; p.seed_off = seed_off; p.salt = g_ds6g_salt;
     const int ntiles = cdiv(T, 32);
@@ -966,7 +1131,7 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
         float* wsf = (float*)((char*)ws + hand);
         const size_t wsb = ws_bytes - hand;
         hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((long)B * T * nh, 256)), dim3(256), 0, st, o, d_o, delta, B, T, nh,
-                           hd, ld, o16);
+                           hd, ld, o16 | (in16 << 1));
         DS6G_LAUNCH_CHECK();
         auto plan = [&](int per_cu, size_t slabs_per_split) {
             const size_t cap = wsb / (slabs_per_split * slab * sizeof(float));
@@ -1009,7 +1174,7 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
         return DS6G_OK;
     }
     // the recomputing form reads o inside its dQ kernel (fp32 only): the bf16-storage path needs the hand-over workspace
-    DS6G_CHECK_ARG(!o16);
+    DS6G_CHECK_ARG(!o16 && !in16);
     // ---- dQ (split over keys)
     {
         const size_t max_by_ws = ws ? ws_bytes / (slab * sizeof(float)) : 1;
@@ -1052,7 +1217,7 @@ int ds6g_attention_bwd(const float* q, const float* k, const float* v, const flo
                        const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int T, int nh, int hd,
                        int ld_qkv, int ld, int ld_dqkv, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
                        size_t ws_bytes, void* stream) {
-    return attention_bwd_impl(q, k, v, o, 0, d_o, lse, delta, dq, dk, dv, 0, B, T, nh, hd, ld_qkv, ld, ld_dqkv, drop_p, seed,
+    return attention_bwd_impl(q, k, v, 0, o, 0, d_o, lse, delta, dq, dk, dv, 0, B, T, nh, hd, ld_qkv, ld, ld_dqkv, drop_p, seed,
                               seed_off, ws, ws_bytes, stream);
 }
 // bf16-storage path: o (the forward output) is bf16, dq / dk / dv are written as bf16 [B*T][ld_dqkv]; q / k / v / d_o fp32.
@@ -1061,8 +1226,18 @@ int ds6g_attention_bwd_bf16(const float* q, const float* k, const float* v, cons
                             const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int T, int nh, int hd,
                             int ld_qkv, int ld, int ld_dqkv, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
                             size_t ws_bytes, void* stream) {
-    return attention_bwd_impl(q, k, v, (const float*)o, 1, d_o, lse, delta, (float*)dq, (float*)dk, (float*)dv, 1, B, T, nh, hd,
+    return attention_bwd_impl(q, k, v, 0, (const float*)o, 1, d_o, lse, delta, (float*)dq, (float*)dk, (float*)dv, 1, B, T, nh, hd,
                               ld_qkv, ld, ld_dqkv, drop_p, seed, seed_off, ws, ws_bytes, stream);
+}
+// all operands bf16: q / k / v / o / d_o in, dq / dk / dv out (the hand-over tiles in ws, lse and delta stay fp32)
+int ds6g_attention_bwd_bf16io(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                              float* delta, void* dq, void* dk, void* dv, int B, int T, int nh, int hd, int ld_qkv, int ld,
+                              int ld_dqkv, float drop_p, uint64_t seed, uint64_t seed_off, void* ws, size_t ws_bytes,
+                              void* stream) {
+    DS6G_CHECK_ARG(ld_qkv % 8 == 0 && ld % 8 == 0 && ld_dqkv % 4 == 0);
+    return attention_bwd_impl((const float*)q, (const float*)k, (const float*)v, 1, (const float*)o, 1, (const float*)d_o, lse, delta,
+                              (float*)dq, (float*)dk, (float*)dv, 1, B, T, nh, hd, ld_qkv, ld, ld_dqkv, drop_p, seed, seed_off, ws,
+                              ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -846,7 +846,10 @@ int run_wgrad(IgemmParams& p, float* dw, int accumulate, float* dbias, int accum
     const long tiles = (long)cdiv(p.Mg, tile == 1 ? 128 : 64) * cdiv(p.Ng, 64);
     // measured on gfx950 (tools/bench_igemm.py): convs are fastest with ~2048 workgroups in flight, the GPT
     // linears (large outputs, costlier slab reduction) with ~1024
-    const long target_blocks = p.is_linear ? 1024 : 2048;
+    static long t_lin = -1, t_conv = -1;   // env overrides for tuning sweeps
+    if (t_lin < 0) { const char* e = getenv("DS6G_WGRAD_TARGET_LIN"); t_lin = e ? atol(e) : 1024; }
+    if (t_conv < 0) { const char* e = getenv("DS6G_WGRAD_TARGET_CONV"); t_conv = e ? atol(e) : 2048; }
+    const long target_blocks = p.is_linear ? t_lin : t_conv;
     long splits = (target_blocks + tiles - 1) / tiles;
     const long max_by_k = (p.Kg + 64 - 1) / 64;
     if (splits > max_by_k) splits = max_by_k;

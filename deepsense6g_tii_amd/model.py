@@ -771,9 +771,9 @@ class TransFuser(nn.Module):
         return out, (x, c1, a1, s1, c2, (stats[0], stats[1]), cd, sd, out, ud1, ud2)
 
     def _gpt_block_fwd16(self, blk, x, B, T, train):
-        """_gpt_block_fwd on bf16-stored GEMM operands: LN -> h (bf16) -> fused k|q|v GEMM (fp32 out: the attention kernels
-        stage fp32 tiles) -> attention (o written as bf16) -> proj GEMM + dropout + residual (fp32 stream) -> LN -> h2 (bf16)
-        -> fc1 + ReLU (bf16) -> fc2 + dropout + residual (fp32).  Same dropout counters / masks as the fp32-storage path."""
+        """_gpt_block_fwd on bf16-stored operands: LN -> h (bf16) -> fused k|q|v GEMM (bf16) -> attention on bf16 tiles (o
+        bf16) -> proj GEMM + dropout + residual (fp32 stream) -> LN -> h2 (bf16) -> fc1 + ReLU (bf16) -> fc2 + dropout +
+        residual (fp32).  Same dropout counters / masks as the fp32-storage path."""
         cfg = self.config
         C = x.shape[1]
         nh = cfg.n_head
@@ -781,10 +781,10 @@ class TransFuser(nn.Module):
         pr = cfg.resid_pdrop if train else 0.0
         at = blk.attn
         h, m1, r1 = ops.layernorm_fwd_bf16(x, self._w(blk.ln1.weight), self._w(blk.ln1.bias), blk.ln1.eps)
-        kqv = ops.bf16_linear_fwd(h, self._w16(at.key.weight), self._w(at.key.bias), 3 * C, out16=False)
+        kqv = ops.bf16_linear_fwd(h, self._w16(at.key.weight), self._w(at.key.bias), 3 * C)   # bf16 [M, 3C]
         k, q, v = kqv[:, :C], kqv[:, C:2 * C], kqv[:, 2 * C:]
         off_a = self._next_drop(B * nh * T * T) if pa > 0 else 0
-        y, lse = ops.attention_fwd_bf16out(q, k, v, B, T, nh, self._ws, pa, self._seed, off_a)
+        y, lse = ops.attention_fwd_bf16(q, k, v, B, T, nh, self._ws, pa, self._seed, off_a)
         off_p = self._next_drop(x.numel()) if pr > 0 else 0
         x1 = ops.bf16_linear_fwd(y, self._w16(at.proj.weight), self._w(at.proj.bias), C, residual=x, drop_p=pr,
                                  seed=self._seed, seed_off=off_p)
@@ -819,10 +819,10 @@ class TransFuser(nn.Module):
         dx1, dz1 = ops.layernorm_bwd_bf16(dh2, x1, m2, r2, self._w(blk.ln2.weight), g2w, g2b, self._ws, add=dx2,
                                           accumulate=bool(a2), drop=(pr, self._seed, off_p))
         wgrad(at.proj.weight, at.proj.bias, y, dz1)
-        dy = ops.bf16_linear_dgrad(dz1, self._w16(at.proj.weight), C, out16=False)   # fp32: the attention backward's dO
+        dy = ops.bf16_linear_dgrad(dz1, self._w16(at.proj.weight), C)   # bf16: the attention backward's dO
         dkqv = torch.empty((dy.shape[0], 3 * C), dtype=torch.bfloat16, device=dy.device)
-        ops.attention_bwd_bf16(q, k, v, y, dy, lse, B, T, nh, self._attn_ws(B, T, nh, C), pa, self._seed, off_a,
-                               out=(dkqv[:, C:2 * C], dkqv[:, :C], dkqv[:, 2 * C:]))
+        ops.attention_bwd_bf16io(q, k, v, y, dy, lse, B, T, nh, self._attn_ws(B, T, nh, C), pa, self._seed, off_a,
+                                 out=(dkqv[:, C:2 * C], dkqv[:, :C], dkqv[:, 2 * C:]))
         wgrad(at.key.weight, at.key.bias, h, dkqv)   # the fused [3C, C] block and its [3C] bias start at key.*
         dh = ops.bf16_linear_dgrad(dkqv, self._w16(at.key.weight), C)
         g1w, a1 = self._g(blk.ln1.weight)

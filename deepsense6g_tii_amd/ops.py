@@ -549,3 +549,44 @@ def bn_bwd_maxpool_bf16in(dpool, idx, x, mean, invstd, gamma_ptr, beta_ptr, dgam
     lib().bn_bwd_maxpool_bf16in(_p(dpool), _p(idx), _p(x), _p(mean), _p(invstd), gamma_ptr, beta_ptr, _p(dx), dgamma_ptr,
                                 dbeta_ptr, N, H, W, C, int(accumulate), ws.ptr, ws.nbytes, _stream())
     return dx
+
+
+def _rows16(t, M, C):
+    assert t.dtype == BF16 and t.is_cuda and tuple(t.shape) == (M, C) and t.stride(1) == 1 and t.stride(0) % 8 == 0, \
+        (t.dtype, tuple(t.shape), t.stride())
+    return t.stride(0)
+
+
+def attention_fwd_bf16(q, k, v, B, T, nh, ws: Workspace, drop_p=0.0, seed=0, seed_off=0):
+    """all-bf16 attention: q, k, v [B*T, C] bf16 (column blocks of one fused projection output allowed) -> (o bf16, lse fp32)"""
+    M, C = q.shape
+    assert M == B * T
+    ldq = _rows16(q, M, C)
+    assert _rows16(k, M, C) == ldq and _rows16(v, M, C) == ldq
+    o = torch.empty((M, C), dtype=BF16, device=q.device)
+    lse = torch.empty((B, nh, T), dtype=F32, device=q.device)
+    lib().attention_fwd_bf16(_p(q), _p(k), _p(v), _p(o), _p(lse), B, T, nh, C // nh, ldq, C, float(drop_p), seed, seed_off,
+                             ws.ptr, ws.nbytes, _stream())
+    return o, lse
+
+
+def attention_bwd_bf16io(q, k, v, o, d_o, lse, B, T, nh, ws: Workspace, drop_p=0.0, seed=0, seed_off=0, out=None):
+    """all-bf16 backward: q, k, v, o, d_o bf16 -> dq, dk, dv bf16 (`out`: three [B*T, C] bf16 views of one row stride)"""
+    M, C = q.shape
+    ldq = _rows16(q, M, C)
+    assert _rows16(k, M, C) == ldq and _rows16(v, M, C) == ldq
+    _chk16(o, M, C)
+    _chk16(d_o, M, C)
+    _chk(lse, B, nh, T)
+    assert ws.nbytes >= int(lib().attention_workspace_bytes(B, T, nh, C // nh, C)), "attention_bwd_bf16io needs the hand-over workspace"
+    delta = torch.empty_like(lse)
+    if out is None:
+        out = tuple(torch.empty((M, C), dtype=BF16, device=q.device) for _ in range(3))
+    dq, dk, dv = out
+    for t in out:
+        assert t.dtype == BF16 and tuple(t.shape) == (M, C) and t.stride(1) == 1 and t.stride(0) % 4 == 0
+    ldd = dq.stride(0)
+    assert dk.stride(0) == ldd and dv.stride(0) == ldd
+    lib().attention_bwd_bf16io(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, T, nh,
+                               C // nh, ldq, C, ldd, float(drop_p), seed, seed_off, ws.ptr, ws.nbytes, _stream())
+    return dq, dk, dv

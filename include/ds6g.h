@@ -200,6 +200,18 @@ int ds6g_attention_bwd_bf16(const float* q, const float* k, const float* v, cons
                             int ld_qkv, int ld, int ld_dqkv, float drop_p, uint64_t seed, uint64_t seed_off, void* ws,
                             size_t ws_bytes, void* stream);
 
+/* all operands bf16 in HBM (q / k / v [B*T][ld_qkv], o / d_o [B*T][ld], dq / dk / dv [B*T][ld_dqkv]): K / V / Q / dO tiles are
+ * staged as bf16 LDS images by LDS-DMA and reach v_mfma_f32_32x32x16_bf16 unconverted (row reads: ds_read_b128, transposed
+ * reads for the P.V / dS^T.Q / P^T.dO / dS.K products: ds_read_b64_tr_b16); lse, delta, the split slabs and the dS / P
+ * hand-over tiles stay fp32.  ld_qkv and ld multiples of 8. */
+int ds6g_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, float* lse, int B, int T, int nh, int hd,
+                            int ld_qkv, int ld, float drop_p, uint64_t seed, uint64_t seed_off, void* ws, size_t ws_bytes,
+                            void* stream);
+int ds6g_attention_bwd_bf16io(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                              float* delta, void* dq, void* dk, void* dv, int B, int T, int nh, int hd, int ld_qkv, int ld,
+                              int ld_dqkv, float drop_p, uint64_t seed, uint64_t seed_off, void* ws, size_t ws_bytes,
+                              void* stream);
+
 /* ---- input.hip : device-side counterpart of CARLA_Data.__getitem__, data2_seq.py:42-173 --------
  * pack_image_u8: decoded RGB frame batch [B][H][W][3] uint8 (data2_seq.py:110-141, before its HWC->CHW transpose) ->
  *   frame slot t of the NHWC x4 stem input [(b*frames_per_sample + t)][H][W][4], cast + normalize_imagenet

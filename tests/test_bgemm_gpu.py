@@ -288,3 +288,49 @@ def test_bf16_stem_pool_layernorm_attention_and_spatial_variants(dev):
     L.head_bwd(dfu.data_ptr(), h32.data_ptr(), Nf, 512, fps, st)
     one_rounding(h16, h32)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,T,nh,hd", [(2, 962, 4, 16), (2, 962, 4, 32), (2, 333, 4, 64), (1, 962, 4, 128), (12, 962, 4, 128), (3, 77, 2, 64)])
+def test_bf16_stored_attention_fwd_bwd(dev, B, T, nh, hd):
+    """all-bf16 attention (bf16 LDS images, transposed LDS reads) against an fp64 reference on the same bf16-rounded
+    q / k / v / dO, dropout off: the kernel rounds P (and dS) to bf16 for the second products, so outputs agree to the
+    builder-declared 2e-2 of the largest value (the bar of the operand-rounding mode, tests/test_bf16_gpu.py); against the
+    fp32-storage kernel in bf16 mode on the same inputs - same roundings except q.scale - to 1e-2.  Fused-qkv layout (row
+    stride 3C) included, and with dropout the two paths must draw the same mask."""
+    from deepsense6g_tii_amd import ops
+    from deepsense6g_tii_amd._lib import lib
+    C = nh * hd
+    g = torch.Generator().manual_seed(T + hd + B)
+    kqv = r16(torch.randn(B * T, 3 * C, generator=g)).cuda()
+    k, q, v = kqv[:, :C], kqv[:, C:2 * C], kqv[:, 2 * C:]
+    do = r16(torch.randn(B * T, C, generator=g)).cuda()
+    ws = ops.Workspace(dev, int(lib().attention_workspace_bytes(B, T, nh, hd, C)) + (64 << 20))
+    o16, lse = ops.attention_fwd_bf16(q, k, v, B, T, nh, ws)
+    dkqv = torch.full((B * T, 3 * C), float("nan"), dtype=BF, device=dev)
+    ops.attention_bwd_bf16io(q, k, v, o16, do, lse, B, T, nh, ws, out=(dkqv[:, C:2 * C], dkqv[:, :C], dkqv[:, 2 * C:]))
+    torch.cuda.synchronize()
+    assert torch.isfinite(dkqv.float()).all()
+    # fp64 reference
+    qd, kd, vd, dod = (t.double().cpu().requires_grad_(True) for t in (q, k, v, do))
+    heads = lambda t: t.view(B, T, nh, hd).transpose(1, 2)  # noqa: E731
+    att = torch.softmax((heads(qd) @ heads(kd).transpose(-2, -1)) / math.sqrt(hd), dim=-1)
+    oref = (att @ heads(vd)).transpose(1, 2).reshape(B * T, C)
+    oref.backward(dod.detach())
+    def rel(a, b):
+        return ((a.double().cpu() - b).abs().max() / b.abs().max()).item()
+    errs = dict(o=rel(o16, oref.detach()), dq=rel(dkqv[:, C:2 * C], qd.grad), dk=rel(dkqv[:, :C], kd.grad), dv=rel(dkqv[:, 2 * C:], vd.grad))
+    print("bf16-stored attention errors", hd, errs)
+    assert max(errs.values()) < 2e-2, errs
+    # the fp32-storage kernel in bf16 matrix mode on the same values
+    ops.set_compute_mode("bf16")
+    try:
+        o32, lse32 = ops.attention_fwd(q.float(), k.float(), v.float(), B, T, nh, ws)
+        ref = ops.attention_bwd(q.float(), k.float(), v.float(), o32, do.float(), lse32, B, T, nh, ws)
+        od16, _ = ops.attention_fwd_bf16(q, k, v, B, T, nh, ws, 0.1, 5, 4096)
+        od32, _ = ops.attention_fwd(q.float(), k.float(), v.float(), B, T, nh, ws, 0.1, 5, 4096)
+    finally:
+        ops.set_compute_mode("f32")
+    assert rel(o16, o32.double().cpu()) < 1e-2 and (lse - lse32).abs().max().item() < 1e-2
+    for a, b in zip((dkqv[:, C:2 * C], dkqv[:, :C], dkqv[:, 2 * C:]), ref):
+        assert rel(a, b.double().cpu()) < 1e-2
+    assert rel(od16, od32.double().cpu()) < 1e-2      # same (seed, offset) -> same dropout mask
