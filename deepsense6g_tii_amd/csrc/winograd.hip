@@ -23,6 +23,14 @@ void ds6g_prof_close(void* rec, hipStream_t st);
 
 int g_wino_kb64 = 0;  // timing experiments: 64 output channels per workgroup, one wave per SIMD (measured slower)
 
+// timing ablations of the forward kernel (env DS6G_WINO_DBG) exist only in a -DDS6G_WINO_ABLATE build: in the shipped build the
+// tests fold away, so the chunk loop has no control flow between the MFMA chain and the input transform
+#ifdef DS6G_WINO_ABLATE
+#define WINO_DBG(bit) (p.dbg & (bit))
+#else
+#define WINO_DBG(bit) false
+#endif
+
 namespace {
 
 constexpr int WG_TILES = 32;   // tiles per workgroup (MFMA rows)
@@ -150,14 +158,14 @@ __global__ __launch_bounds__(256, (TNK == 1 ? 2 : 1)) void winograd_fwd_kernel(c
     f32x2 raw[16];
     f32x4 ub[4][TNK][2];
     auto prefetch = [&](int c0) {
-        if (!(p.dbg & 1))
+        if (!WINO_DBG(1))
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const auto v = __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, xoff[e], (unsigned)(c0 * 4), 0);
             raw[e][0] = __uint_as_float(v[0]);
             raw[e][1] = __uint_as_float(v[1]);
         }
-        if (!(p.dbg & 2))
+        if (!WINO_DBG(2))
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(256, (TNK == 1 ? 2 : 1)) void winograd_fwd_kernel(c
     // input transform of the prefetched patch, V = B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], written to
     // V buffer `vb` (two buffers: the transform of chunk c+1 is written while other waves still multiply chunk c)
     auto transform_store = [&](int vb) {
-        if (p.dbg & 4) return;
+        if (WINO_DBG(4)) return;
         f32x2 t[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(256, (TNK == 1 ? 2 : 1)) void winograd_fwd_kernel(c
         if (more) prefetch((ck + 1) * WG_CH);  // patch + U fragments of the next chunk fly under the MFMAs below
         // ---- 4 positions x 8 MFMAs: acc[q] += V_pos[tiles][16] * U_pos[k][16]^T ----
         const float* vbuf = lds + (ck & 1) * (16 * 512);
-        if (!(p.dbg & 8))
+        if (!WINO_DBG(8))
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float* vrow = vbuf + ((wave * 4 + q) * 2048 + a_src) / 4;
