@@ -336,12 +336,15 @@ class TransFuser(nn.Module):
         self._ws_main = ops.Workspace(dev, 1 << 30)
         self._anchor = torch.zeros(1, dtype=F32, device=dev, requires_grad=True)
         self._pname = {id(p): n for n, p in named}
+        # the hot path walks the parameter list several times per step (fresh / accumulate modes, arena check, zero_grad):
+        # nn.Module.named_parameters() re-traverses the module tree each time (~3 ms of host per walk), the set is fixed
+        self._plist = list(self.named_parameters())
 
     @property
     def _ws(self):
         """scratch of the stream the caller is launching on (a scratch buffer is only safe within one stream)"""
         if self._ws_side:
-            ws = self._ws_side.get(torch.cuda.current_stream().cuda_stream)
+            ws = self._ws_side.get(ops._stream())
             if ws is not None:
                 return ws
         return self._ws_main
@@ -394,7 +397,7 @@ class TransFuser(nn.Module):
 
     def params_in_arena(self):
         a0 = self._arena.data_ptr()
-        for name, p in self.named_parameters():
+        for name, p in self._plist:
             off, _ = self._pslice[name]
             if p.data_ptr() != a0 + 4 * off:
                 return False
@@ -433,10 +436,11 @@ class TransFuser(nn.Module):
         # .grad is None -> write fresh and attach the arena view; .grad is our view -> accumulate in
         # place (torch semantics when zero_grad was not called); foreign tensor -> write, then add.
         self._gmode, self._fresh, self._foreign = {}, [], []
+        plist = self._plist if self._arena is not None else list(self.named_parameters())
         if self.grad_ready_hook is not None:
             # data parallel: a bucket is all-reduced in place the moment it is final, so every gradient must be written
             # fresh this step - accumulating into an already-reduced arena would sum the earlier steps world times over
-            bad = [n for n, p in self.named_parameters() if p.grad is not None]
+            bad = [n for n, p in self._plist if p.grad is not None]
             if bad:
                 raise RuntimeError(f"data-parallel backward needs zero_grad(set_to_none=True) first; {len(bad)} parameters "
                                    f"still hold a gradient (e.g. {bad[0]}): gradient accumulation across steps is not "
@@ -444,7 +448,7 @@ class TransFuser(nn.Module):
             begin = getattr(self.grad_ready_hook, "__self__", None)
             if begin is not None and hasattr(begin, "begin"):
                 begin.begin()
-        for name, p in self.named_parameters():
+        for name, p in plist:
             gv = self._gview[name]
             if p.grad is None:
                 self._fresh.append((p, gv))

@@ -91,7 +91,7 @@ class FusedAdamW:
 
     def zero_grad(self, set_to_none=True):
         if set_to_none:
-            for p in self.model.parameters():
+            for _, p in getattr(self.model, "_plist", None) or self.model.named_parameters():
                 p.grad = None
         else:
             self.model.flat_parameters()[1].zero_()
