@@ -52,6 +52,7 @@ struct WinoParams {
     const float* residual;  //   identity branch [N][H][W][K],
     int relu;               //   0 none, 1 before the residual add, 2 after it
     int accumulate;      // y += result (data gradient summed onto the gradient of the residual branch)
+    int items;           // winograd_pc_kernel: work items = tile blocks x K / 64
 };
 
 // U[p][k][c] = (G g G^T)[p], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].  transpose_flip: build the dgrad filter
@@ -303,6 +304,282 @@ __global__ __launch_bounds__(256, (TNK == 1 ? 2 : 1)) void winograd_fwd_kernel(c
 
 
 // ------------------------------------------------------------------------------------------------
+// Producer / consumer form of the forward kernel (the default when K % 64 == 0): the same arithmetic, but the two
+// halves of the chunk loop no longer share a wave.  One PERSISTENT workgroup of 8 waves per CU walks a list of work
+// items (32 tiles x 64 output channels each); waves 0-3 (one per SIMD) only multiply - wave w owns the position row
+// 4w..4w+3 x two 32-channel blocks, 64 MFMAs per 16-channel chunk, its U fragments refilled in place one chunk ahead
+// right after the MFMAs that read them - and waves 4-7 only move data: patch loads one chunk ahead, B^T d B, the V image
+// of the NEXT chunk (double-buffered), and the output transform + stores of the PREVIOUS item while the multipliers
+// are already in the next one.  One barrier per chunk; the chunk sequence runs across item boundaries, so prologue and
+// output transform are paid once per workgroup, not once per item.  The multipliers fold the column half of A^T M A
+// in registers (their four positions are one row of the 4x4 grid), which halves the LDS hand-over image.
+#define PC_DBG(bit) ((DBG & (bit)) != 0)  // compile-time ablations (a -DDS6G_WINO_ABLATE build instantiates them)
+constexpr int PC_KB = 64;                                     // output channels per item
+constexpr int PC_V_FLOATS = 2 * 16 * WG_TILES * WG_CH;        // two V images            (64 KiB)
+constexpr int PC_S_FLOATS = 4 * 2 * WG_TILES * PC_KB;         // S = M A per position row (64 KiB)
+constexpr int PC_LDS_BYTES = (PC_V_FLOATS + PC_S_FLOATS) * 4;
+
+template <int DBG>
+__global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p) {
+    extern __shared__ __attribute__((aligned(16))) float pc_lds[];
+    float* const Vl = pc_lds;                // [2][16 positions][32 tiles][16 ch], swizzled as in winograd_fwd_kernel
+    float* const Sl = pc_lds + PC_V_FLOATS;  // [4 rows][2][32 tiles][64 k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const bool consumer = wave < 4;
+    const int kblocks = p.K / PC_KB;
+    const int G = (int)gridDim.x;
+    const int nchunks = p.C / WG_CH;
+    const int my_items = (p.items - (int)blockIdx.x + G - 1) / G;
+    const int T = my_items * nchunks;  // chunk steps of this workgroup
+
+    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
+    const unsigned upos = (unsigned)((size_t)p.K * p.C * 4);  // bytes between positions of U
+
+    // ---------------- multiplier state ----------------
+    f32x16 acc[4][2];
+    f32x4 ub[4][2][2];
+    const unsigned a_src = (unsigned)(l31 * 64);
+    const int swz = (l31 >> 2) & 3;
+    // byte offset (scalar) of the U fragment block of (item, chunk) for position row `wave`, q = 0, j = 0
+    auto u_soff = [&](int item, int ck) -> unsigned {
+        const int kb = item % kblocks;
+        return (unsigned)(wave * 4) * upos + (unsigned)(((kb * (PC_KB / 32)) * (p.C >> 4) + ck) * 2048);
+    };
+    auto load_u = [&](int q, int j, unsigned soff) {
+        if (PC_DBG(2)) return;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, (unsigned)(lane * 32 + h * 16),
+                                                                 soff + (unsigned)q * upos + (unsigned)(j * (p.C >> 4) * 2048), 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ub[q][j][h][e] = __uint_as_float(v[e]);
+        }
+    };
+
+    // ---------------- mover state (waves 4-7): one (tile, channel pair) transform item per thread ----------------
+    const int ptid = tid & 255;
+    const int tt = ptid >> 3, cp = ptid & 7;
+    // LDS destination of this thread's V values: position p -> p * 2048 B + tile * 64 B + swizzled channel-pair slot
+    const unsigned vdst = (unsigned)(tt * 64 + ((((cp >> 1) ^ ((tt >> 2) & 3)) << 4) | ((cp & 1) << 3)));
+    unsigned xoff[16];
+    f32x2 rawA[16], rawB[16];  // patches of the odd / even chunk steps (two steps of load latency cover)
+    auto setup_item = [&](int item) __attribute__((always_inline)) {
+        int wg = item / kblocks;
+        const int cb = wg % p.col_blocks, rb = wg / p.col_blocks;
+        const int trow = rb * p.BTH + tt / p.BTW, tcol = cb * p.BTW + tt % p.BTW;
+        const bool tile_ok = trow < p.rows_total;
+        const int n = tile_ok ? trow / p.TH : 0;
+        const int th = tile_ok ? trow - n * p.TH : 0;
+        const int ih0 = 2 * th - 1, iw0 = 2 * tcol - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ih = ih0 + i, iw = iw0 + j;
+                const bool ok = tile_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                xoff[i * 4 + j] = ok ? (unsigned)((((n * p.H + ih) * p.W + iw) * p.C + cp * 2) * 4) : OOB_OFF;
+            }
+    };
+    auto load_patch = [&](int ck, f32x2 (&raw)[16]) __attribute__((always_inline)) {
+        if (PC_DBG(1)) return;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, xoff[e], (unsigned)(ck * WG_CH * 4), 0);
+            raw[e][0] = __uint_as_float(v[0]);
+            raw[e][1] = __uint_as_float(v[1]);
+        }
+    };
+    auto transform_store = [&](int vb, const f32x2 (&raw)[16]) __attribute__((always_inline)) {
+        if (PC_DBG(4)) return;
+        f32x2 t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0][j] = raw[0 * 4 + j] - raw[2 * 4 + j];
+            t[1][j] = raw[1 * 4 + j] + raw[2 * 4 + j];
+            t[2][j] = raw[2 * 4 + j] - raw[1 * 4 + j];
+            t[3][j] = raw[1 * 4 + j] - raw[3 * 4 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float* base = Vl + vb * (16 * 512) + ((i * 4) * 2048 + vdst) / 4;
+            *reinterpret_cast<f32x2*>(base) = t[i][0] - t[i][2];
+            *reinterpret_cast<f32x2*>(base + 512) = t[i][1] + t[i][2];
+            *reinterpret_cast<f32x2*>(base + 1024) = t[i][2] - t[i][1];
+            *reinterpret_cast<f32x2*>(base + 1536) = t[i][1] - t[i][3];
+        }
+    };
+    // y = A^T S of a finished item, passes [p0, p1) of 8 (a pass = 4 tiles, one per mover wave; lane = output channel);
+    // two passes per round so that the reads of an accumulating / residual epilogue fly together
+    auto epilogue = [&](int item, int p0, int p1) __attribute__((always_inline)) {
+        if (PC_DBG(16)) return;
+        const int kb = item % kblocks;
+        const int wg = item / kblocks;
+        const int cb = wg % p.col_blocks, rb = wg / p.col_blocks;
+        const int kk = lane;
+        const float bb = p.bias ? p.bias[kb * PC_KB + kk] : 0.f;
+        const float* side = p.accumulate ? p.y : p.residual;  // what is added to the result (either or none)
+        const int pw = wave & 3;  // the tile of a pass is uniform over the wave: its address arithmetic is scalar
+        const size_t rowstride = (size_t)p.W * p.K;
+        for (int pp = p0; pp < p1; pp += 2) {
+            float* op[2];
+            bool ok[2];
+            float old[2][4];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int tile = ((pp + b) & 7) * 4 + pw;
+                const int orow = rb * p.BTH + tile / p.BTW, ocol = cb * p.BTW + tile % p.BTW;
+                ok[b] = pp + b < p1 && orow < p.rows_total;
+                const int on = orow / p.TH, oth = orow - on * p.TH;
+                const size_t oi = ((size_t)(on * p.H + 2 * oth) * p.W + 2 * ocol) * p.K + (size_t)(kb * PC_KB);
+                op[b] = p.y + oi + kk;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) old[b][i] = 0.f;
+                if (side && ok[b]) {
+                    const float* sp = side + oi + kk;
+                    old[b][0] = sp[0];
+                    old[b][1] = sp[p.K];
+                    old[b][2] = sp[rowstride];
+                    old[b][3] = sp[rowstride + p.K];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int tile = ((pp + b) & 7) * 4 + pw;
+                float s[4][2];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) s[r][c] = Sl[((r * 2 + c) * WG_TILES + tile) * PC_KB + kk];
+                float y[4];
+                y[0] = s[0][0] + s[1][0] + s[2][0];
+                y[1] = s[0][1] + s[1][1] + s[2][1];
+                y[2] = s[1][0] - s[2][0] - s[3][0];
+                y[3] = s[1][1] - s[2][1] - s[3][1];
+                if (p.accumulate) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] += old[b][i];
+                } else if (p.bias || p.residual || p.relu) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = y[i] + bb;
+                        if (p.relu == 1) v = fmaxf(v, 0.f);
+                        v += old[b][i];
+                        if (p.relu == 2) v = fmaxf(v, 0.f);
+                        y[i] = v;
+                    }
+                }
+                if (ok[b]) {
+                    float* o = op[b];
+                    o[0] = y[0];
+                    o[p.K] = y[1];
+                    o[rowstride] = y[2];
+                    o[rowstride + p.K] = y[3];
+                }
+            }
+        }
+    };
+
+    // The two roles run separate loops with the same number of barriers (T + 1), so neither holds the other's registers.
+    if (consumer) {
+        int it_cur = (int)blockIdx.x, ck_cur = 0;  // chunk step t
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][j][r] = 0.f;
+                load_u(q, j, u_soff(it_cur, 0));
+            }
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const bool last_of_item = ck_cur + 1 == nchunks;
+            const int it_nxt = last_of_item ? it_cur + G : it_cur;
+            const int ck_nxt = last_of_item ? 0 : ck_cur + 1;
+            // U of the next chunk step (the last step re-reads its own: no branch in the chain)
+            const bool more = t + 1 < T;
+            const unsigned soff = u_soff(more ? it_nxt : it_cur, more ? ck_nxt : ck_cur);
+            const float* vbuf = Vl + (t & 1) * (16 * 512);
+            auto read_a = [&](int q, f32x4& a0, f32x4& a1) {
+                const float* vrow = vbuf + ((wave * 4 + q) * 2048 + a_src) / 4;
+                a0 = *reinterpret_cast<const f32x4*>(vrow + (((khalf * 2 + 0) ^ swz) << 2));
+                a1 = *reinterpret_cast<const f32x4*>(vrow + (((khalf * 2 + 1) ^ swz) << 2));
+            };
+            f32x4 a0, a1, n0, n1;
+            read_a(0, a0, a1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < 3) read_a(q + 1, n0, n1);  // the next position's fragments land under this one's MFMAs
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (!PC_DBG(8)) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], ub[q][j][0][e], acc[q][j], 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], ub[q][j][1][e], acc[q][j], 0, 0, 0);
+                    }
+                    load_u(q, j, soff);  // refill in place for the next chunk step: a whole step of latency cover
+                    __builtin_amdgcn_sched_barrier(0);  // ... which only holds if the refill stays here
+                }
+                a0 = n0;
+                a1 = n1;
+            }
+            if (last_of_item) {
+                // S = M A for this wave's position row: columns (1 1 1 0) and (0 1 -1 -1)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int tile = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                        const float m0 = acc[0][j][r], m1 = acc[1][j][r], m2 = acc[2][j][r], m3 = acc[3][j][r];
+                        Sl[((wave * 2 + 0) * WG_TILES + tile) * PC_KB + j * 32 + l31] = m0 + m1 + m2;
+                        Sl[((wave * 2 + 1) * WG_TILES + tile) * PC_KB + j * 32 + l31] = m1 - m2 - m3;
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[q][j][r] = 0.f;
+            }
+            __syncthreads();
+            it_cur = it_nxt;
+            ck_cur = ck_nxt;
+        }
+    } else {
+        int it_cur = (int)blockIdx.x, ck_cur = 0;  // chunk step t (what the multipliers are on)
+        int it_ld = it_cur, ck_ld = 0;             // the chunk step whose patch loads were issued last
+        auto next_load = [&](f32x2 (&raw)[16]) __attribute__((always_inline)) {
+            if (++ck_ld == nchunks) { ck_ld = 0; it_ld += G; setup_item(it_ld); }
+            load_patch(ck_ld, raw);
+        };
+        setup_item(it_cur);
+        load_patch(0, rawB);
+        if (T > 1) next_load(rawA);
+        transform_store(0, rawB);
+        __syncthreads();
+        // step t: rcur holds the patch of chunk step t + 1, rnext is free for the loads of step t + 2
+        auto step = [&](int t, const f32x2 (&rcur)[16], f32x2 (&rnext)[16]) __attribute__((always_inline)) {
+            if (t + 2 < T) next_load(rnext);
+            if (t + 1 < T) transform_store((t + 1) & 1, rcur);
+            // the item the multipliers finished one step ago (in one piece: spreading the passes over the item's steps,
+            // and giving the stores waves of their own, were both measured slower)
+            if (ck_cur == 0 && t > 0) epilogue(it_cur - G, 0, 8);
+            __syncthreads();
+            if (++ck_cur == nchunks) { ck_cur = 0; it_cur += G; }
+        };
+        for (int t = 0; t < T; t += 2) {
+            step(t, rawA, rawB);
+            if (t + 1 < T) step(t + 1, rawB, rawA);
+        }
+        epilogue(it_cur - G, 0, 8);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight gradient of the same convolutions in the Winograd domain: the forward is linear in U = G g G^T, so
 //     dU_p[k][c] = sum_tiles E_p[tile][k] * V_p[tile][c],   E = A dY A^T (2x2 -> 4x4),   V = B^T d B,
 //     dW = G^T dU G   (4x4 -> 3x3, winograd_wgrad_finish_kernel, which also sums the split slabs)
@@ -551,6 +828,17 @@ int ds6g_conv3x3_winograd_bias_act_fwd(const float* x, const float* u, const flo
     return wino_fwd_launch(x, u, y, N, H, W, C, K, 0, bias, residual, relu, stream);
 }
 
+static bool pc_set_lds() {
+    bool ok = true;
+#define PC_ATTR(D) ok = ok && hipFuncSetAttribute((const void*)winograd_pc_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS_BYTES) == hipSuccess;
+    PC_ATTR(0)
+#ifdef DS6G_WINO_ABLATE
+    PC_ATTR(1) PC_ATTR(2) PC_ATTR(3) PC_ATTR(4) PC_ATTR(7) PC_ATTR(8) PC_ATTR(16) PC_ATTR(24) PC_ATTR(9) PC_ATTR(10) PC_ATTR(18) PC_ATTR(17) PC_ATTR(19) PC_ATTR(32)
+#endif
+#undef PC_ATTR
+    return ok;
+}
+
 static int wino_fwd_launch(const float* x, const float* u, float* y, int N, int H, int W, int C, int K, int accumulate,
                            const float* bias, const float* residual, int relu, void* stream) {
     WinoParams p{};
@@ -566,9 +854,33 @@ static int wino_fwd_launch(const float* x, const float* u, float* y, int N, int 
     p.bias = bias; p.residual = residual; p.relu = relu;
     { const char* e = getenv("DS6G_WINO_DBG"); p.dbg = e ? atoi(e) : 0; }
     const int row_blocks = (p.rows_total + p.BTH - 1) / p.BTH;
+    static const int pc_on = [] { const char* e = getenv("DS6G_WINO_PC"); return e ? atoi(e) : 1; }();
+    const bool use_pc = pc_on && K % PC_KB == 0 && C >= 2 * WG_CH;
+    static int n_cu = 0;  // CUs of the device = persistent workgroups of winograd_pc_kernel
+    if (use_pc && !n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+            !pc_set_lds())
+            return DS6G_ERR_LAUNCH;
+        n_cu = prop.multiProcessorCount;
+    }
     // profiler variant 20000: forward / data gradient; flops = those of the direct 3x3 convolution it replaces
     void* rec = ds6g_prof_open(20000, 2.0 * N * H * W * (double)K * 9.0 * C, (hipStream_t)stream);
-    if (K % (2 * WG_KB) == 0 && g_wino_kb64) {
+    if (use_pc && K % PC_KB == 0 && C >= 2 * WG_CH) {
+        p.items = row_blocks * p.col_blocks * (K / PC_KB);
+        const int grid = p.items < n_cu ? p.items : n_cu;
+#ifdef DS6G_WINO_ABLATE
+        switch (p.dbg) {
+#define PC_CASE(D) case D: hipLaunchKernelGGL(winograd_pc_kernel<D>, dim3((unsigned)grid), dim3(512), PC_LDS_BYTES, (hipStream_t)stream, p); break;
+            PC_CASE(1) PC_CASE(2) PC_CASE(3) PC_CASE(4) PC_CASE(7) PC_CASE(8) PC_CASE(16) PC_CASE(24) PC_CASE(9) PC_CASE(10) PC_CASE(18) PC_CASE(17) PC_CASE(19) PC_CASE(32)
+#undef PC_CASE
+            default: hipLaunchKernelGGL(winograd_pc_kernel<0>, dim3((unsigned)grid), dim3(512), PC_LDS_BYTES, (hipStream_t)stream, p);
+        }
+#else
+        hipLaunchKernelGGL(winograd_pc_kernel<0>, dim3((unsigned)grid), dim3(512), PC_LDS_BYTES, (hipStream_t)stream, p);
+#endif
+    } else if (K % (2 * WG_KB) == 0 && g_wino_kb64) {
         const long blocks = (long)row_blocks * p.col_blocks * (K / (2 * WG_KB));
         hipLaunchKernelGGL(winograd_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     } else {
