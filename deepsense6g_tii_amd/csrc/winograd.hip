@@ -16,6 +16,8 @@
 // The next chunk's patch and U fragments are prefetched into registers while the MFMAs of the current chunk run.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
+#include <cstdio>
 
 // bench instrumentation shared with igemm.hip (ds6g_profile_begin / _end)
 void* ds6g_prof_open(int variant, double flops, hipStream_t st);
@@ -53,6 +55,9 @@ struct WinoParams {
     int relu;               //   0 none, 1 before the residual add, 2 after it
     int accumulate;      // y += result (data gradient summed onto the gradient of the residual branch)
     int items;           // winograd_pc_kernel: work items = tile blocks x K / 64
+    int btw_shift;       //   log2(BTW)
+    unsigned th_magic;   //   ceil(2^32 / TH), TH > 1: row / TH = umulhi(row, th_magic) for row * TH < 2^32
+    unsigned long long* tdbg;  // -DDS6G_WINO_ABLATE, dbg 64: per-step barrier arrive / leave clocks of workgroup 0
 };
 
 // U[p][k][c] = (G g G^T)[p], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].  transpose_flip: build the dgrad filter
@@ -358,126 +363,126 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
         }
     };
 
-    // ---------------- mover state (waves 4-7): one (tile, channel pair) transform item per thread ----------------
-    const int ptid = tid & 255;
-    const int tt = ptid >> 3, cp = ptid & 7;
-    // LDS destination of this thread's V values: position p -> p * 2048 B + tile * 64 B + swizzled channel-pair slot
-    const unsigned vdst = (unsigned)(tt * 64 + ((((cp >> 1) ^ ((tt >> 2) & 3)) << 4) | ((cp & 1) << 3)));
+    // ---------------- mover state (waves 4-7) ----------------
+    // Beside a wave that issues fp32 32x32x2 MFMAs back to back its SIMD partner gets about ONE vector instruction (VALU,
+    // LDS or VMEM alike) per MFMA (tools/mfma_valu_coexec.hip): the movers' budget is 64 instruction slots per chunk step, so
+    // everything here is 16 bytes wide.  Transform item = (tile, 4 channels): 128 items per chunk = two waves; waves 4, 5
+    // produce the even chunk steps and waves 6, 7 the odd ones, each over TWO steps (stage A: column pass of B^T d B and
+    // the loads two chunks on; stage B: row pass and the V image), so that every SIMD's mover has half an item per step.
+    const int mw = wave & 3;
+    const int pair = mw >> 1;                        // parity of the chunk steps this wave produces
+    const int tt = (mw & 1) * 16 + (lane >> 2);      // tile of the transform item
+    const int cq = lane & 3;                         // channel quad within the 16-channel chunk
+    const unsigned vdst = (unsigned)(tt * 64 + ((cq ^ ((tt >> 2) & 3)) << 4));  // bytes within a position's [32][16] image
     unsigned xoff[16];
-    f32x2 rawA[16], rawB[16];  // patches of the odd / even chunk steps (two steps of load latency cover)
+    f32x4 raw[16], tc[16];
     auto setup_item = [&](int item) __attribute__((always_inline)) {
-        int wg = item / kblocks;
+        const int wg = item / kblocks;
         const int cb = wg % p.col_blocks, rb = wg / p.col_blocks;
-        const int trow = rb * p.BTH + tt / p.BTW, tcol = cb * p.BTW + tt % p.BTW;
+        const int trow = rb * p.BTH + (tt >> p.btw_shift), tcol = cb * p.BTW + (tt & (p.BTW - 1));
         const bool tile_ok = trow < p.rows_total;
-        const int n = tile_ok ? trow / p.TH : 0;
-        const int th = tile_ok ? trow - n * p.TH : 0;
+        const int n = p.TH == 1 ? trow : (int)__umulhi((unsigned)trow, p.th_magic);  // trow / TH
+        const int th = trow - n * p.TH;
         const int ih0 = 2 * th - 1, iw0 = 2 * tcol - 1;
+        const unsigned base = (unsigned)((((n * p.H + ih0) * p.W + iw0) * p.C + cq * 4) * 4);  // may wrap: only used when ok
+        const unsigned rowb = (unsigned)(p.W * p.C * 4), colb = (unsigned)(p.C * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int ih = ih0 + i, iw = iw0 + j;
-                const bool ok = tile_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                xoff[i * 4 + j] = ok ? (unsigned)((((n * p.H + ih) * p.W + iw) * p.C + cp * 2) * 4) : OOB_OFF;
+                const bool ok = tile_ok && (unsigned)(ih0 + i) < (unsigned)p.H && (unsigned)(iw0 + j) < (unsigned)p.W;
+                xoff[i * 4 + j] = ok ? base + (unsigned)i * rowb + (unsigned)j * colb : OOB_OFF;
             }
     };
-    auto load_patch = [&](int ck, f32x2 (&raw)[16]) __attribute__((always_inline)) {
+    auto load_patch = [&](int ck) __attribute__((always_inline)) {
         if (PC_DBG(1)) return;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, xoff[e], (unsigned)(ck * WG_CH * 4), 0);
-            raw[e][0] = __uint_as_float(v[0]);
-            raw[e][1] = __uint_as_float(v[1]);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xoff[e], (unsigned)(ck * WG_CH * 4), 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) raw[e][c] = __uint_as_float(v[c]);
         }
     };
-    auto transform_store = [&](int vb, const f32x2 (&raw)[16]) __attribute__((always_inline)) {
+    // B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: stage A = B^T d (rows), stage B = (.) B and the V image
+    auto stage_a = [&]() __attribute__((always_inline)) {
         if (PC_DBG(4)) return;
-        f32x2 t[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            t[0][j] = raw[0 * 4 + j] - raw[2 * 4 + j];
-            t[1][j] = raw[1 * 4 + j] + raw[2 * 4 + j];
-            t[2][j] = raw[2 * 4 + j] - raw[1 * 4 + j];
-            t[3][j] = raw[1 * 4 + j] - raw[3 * 4 + j];
+            tc[0 * 4 + j] = raw[0 * 4 + j] - raw[2 * 4 + j];
+            tc[1 * 4 + j] = raw[1 * 4 + j] + raw[2 * 4 + j];
+            tc[2 * 4 + j] = raw[2 * 4 + j] - raw[1 * 4 + j];
+            tc[3 * 4 + j] = raw[1 * 4 + j] - raw[3 * 4 + j];
         }
+    };
+    auto stage_b = [&](int vb) __attribute__((always_inline)) {
+        if (PC_DBG(4)) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float* base = Vl + vb * (16 * 512) + ((i * 4) * 2048 + vdst) / 4;
-            *reinterpret_cast<f32x2*>(base) = t[i][0] - t[i][2];
-            *reinterpret_cast<f32x2*>(base + 512) = t[i][1] + t[i][2];
-            *reinterpret_cast<f32x2*>(base + 1024) = t[i][2] - t[i][1];
-            *reinterpret_cast<f32x2*>(base + 1536) = t[i][1] - t[i][3];
+            *reinterpret_cast<f32x4*>(base) = tc[i * 4 + 0] - tc[i * 4 + 2];
+            *reinterpret_cast<f32x4*>(base + 512) = tc[i * 4 + 1] + tc[i * 4 + 2];
+            *reinterpret_cast<f32x4*>(base + 1024) = tc[i * 4 + 2] - tc[i * 4 + 1];
+            *reinterpret_cast<f32x4*>(base + 1536) = tc[i * 4 + 1] - tc[i * 4 + 3];
         }
     };
-    // y = A^T S of a finished item, passes [p0, p1) of 8 (a pass = 4 tiles, one per mover wave; lane = output channel);
-    // two passes per round so that the reads of an accumulating / residual epilogue fly together
-    auto epilogue = [&](int item, int p0, int p1) __attribute__((always_inline)) {
+    // y = A^T S of a finished item, half e (16 tiles) of it: thread = (tile, 4 output channels), 16-byte S reads and stores
+    auto epilogue = [&](int item, int e) __attribute__((always_inline)) {
         if (PC_DBG(16)) return;
         const int kb = item % kblocks;
         const int wg = item / kblocks;
         const int cb = wg % p.col_blocks, rb = wg / p.col_blocks;
-        const int kk = lane;
-        const float bb = p.bias ? p.bias[kb * PC_KB + kk] : 0.f;
-        const float* side = p.accumulate ? p.y : p.residual;  // what is added to the result (either or none)
-        const int pw = wave & 3;  // the tile of a pass is uniform over the wave: its address arithmetic is scalar
+        const int kq = lane & 15;
+        const int tile = e * 16 + mw * 4 + (lane >> 4);
+        const int orow = rb * p.BTH + (tile >> p.btw_shift), ocol = cb * p.BTW + (tile & (p.BTW - 1));
+        const bool ok = orow < p.rows_total;
+        const int on = p.TH == 1 ? orow : (int)__umulhi((unsigned)orow, p.th_magic), oth = orow - on * p.TH;
+        const size_t oi = ((size_t)(on * p.H + 2 * oth) * p.W + 2 * ocol) * p.K + (size_t)(kb * PC_KB + kq * 4);
         const size_t rowstride = (size_t)p.W * p.K;
-        for (int pp = p0; pp < p1; pp += 2) {
-            float* op[2];
-            bool ok[2];
-            float old[2][4];
+        const float* side = p.accumulate ? p.y : p.residual;  // what is added to the result (either or none)
+        f32x4 old[4];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int tile = ((pp + b) & 7) * 4 + pw;
-                const int orow = rb * p.BTH + tile / p.BTW, ocol = cb * p.BTW + tile % p.BTW;
-                ok[b] = pp + b < p1 && orow < p.rows_total;
-                const int on = orow / p.TH, oth = orow - on * p.TH;
-                const size_t oi = ((size_t)(on * p.H + 2 * oth) * p.W + 2 * ocol) * p.K + (size_t)(kb * PC_KB);
-                op[b] = p.y + oi + kk;
+        for (int i = 0; i < 4; ++i) old[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (side && ok) {
+            const float* sp = side + oi;
+            old[0] = *reinterpret_cast<const f32x4*>(sp);
+            old[1] = *reinterpret_cast<const f32x4*>(sp + p.K);
+            old[2] = *reinterpret_cast<const f32x4*>(sp + rowstride);
+            old[3] = *reinterpret_cast<const f32x4*>(sp + rowstride + p.K);
+        }
+        f32x4 s[4][2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) old[b][i] = 0.f;
-                if (side && ok[b]) {
-                    const float* sp = side + oi + kk;
-                    old[b][0] = sp[0];
-                    old[b][1] = sp[p.K];
-                    old[b][2] = sp[rowstride];
-                    old[b][3] = sp[rowstride + p.K];
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                s[r][c] = *reinterpret_cast<const f32x4*>(Sl + ((r * 2 + c) * WG_TILES + tile) * PC_KB + kq * 4);
+        f32x4 y[4];
+        y[0] = s[0][0] + s[1][0] + s[2][0];
+        y[1] = s[0][1] + s[1][1] + s[2][1];
+        y[2] = s[1][0] - s[2][0] - s[3][0];
+        y[3] = s[1][1] - s[2][1] - s[3][1];
+        if (p.accumulate) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] += old[i];
+        } else if (p.bias || p.residual || p.relu) {
+            f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bb = *reinterpret_cast<const f32x4*>(p.bias + kb * PC_KB + kq * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float v = y[i][c] + bb[c];
+                    if (p.relu == 1) v = fmaxf(v, 0.f);
+                    v += old[i][c];
+                    if (p.relu == 2) v = fmaxf(v, 0.f);
+                    y[i][c] = v;
                 }
-            }
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int tile = ((pp + b) & 7) * 4 + pw;
-                float s[4][2];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) s[r][c] = Sl[((r * 2 + c) * WG_TILES + tile) * PC_KB + kk];
-                float y[4];
-                y[0] = s[0][0] + s[1][0] + s[2][0];
-                y[1] = s[0][1] + s[1][1] + s[2][1];
-                y[2] = s[1][0] - s[2][0] - s[3][0];
-                y[3] = s[1][1] - s[2][1] - s[3][1];
-                if (p.accumulate) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] += old[b][i];
-                } else if (p.bias || p.residual || p.relu) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float v = y[i] + bb;
-                        if (p.relu == 1) v = fmaxf(v, 0.f);
-                        v += old[b][i];
-                        if (p.relu == 2) v = fmaxf(v, 0.f);
-                        y[i] = v;
-                    }
-                }
-                if (ok[b]) {
-                    float* o = op[b];
-                    o[0] = y[0];
-                    o[p.K] = y[1];
-                    o[rowstride] = y[2];
-                    o[rowstride + p.K] = y[3];
-                }
-            }
+        }
+        if (ok) {
+            float* o = p.y + oi;
+            *reinterpret_cast<f32x4*>(o) = y[0];
+            *reinterpret_cast<f32x4*>(o + p.K) = y[1];
+            *reinterpret_cast<f32x4*>(o + rowstride) = y[2];
+            *reinterpret_cast<f32x4*>(o + rowstride + p.K) = y[3];
         }
     };
 
@@ -529,14 +534,23 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
             }
             if (last_of_item) {
                 // S = M A for this wave's position row: columns (1 1 1 0) and (0 1 -1 -1)
+                // (the lane's base address is made opaque here so that the 64 store addresses are base + immediate offsets
+                // formed on the spot instead of loop-invariant registers held through the MFMA loop)
+                unsigned so = (unsigned)(wave * (2 * WG_TILES * PC_KB) + khalf * (4 * PC_KB) + l31);
+                asm volatile("" : "+v"(so));  // (an opaque OFFSET: an opaque pointer would lose its LDS address space)
+                float* sb = Sl + so;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int tile = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                        const float m0 = acc[0][j][r], m1 = acc[1][j][r], m2 = acc[2][j][r], m3 = acc[3][j][r];
-                        Sl[((wave * 2 + 0) * WG_TILES + tile) * PC_KB + j * 32 + l31] = m0 + m1 + m2;
-                        Sl[((wave * 2 + 1) * WG_TILES + tile) * PC_KB + j * 32 + l31] = m1 - m2 - m3;
+                    for (int r = 0; r < 16; r += 2) {  // register pairs: packed fp32 adds
+                        const int trow = (r & 3) + 8 * (r >> 2);  // + 4 * khalf = tile (r + 1: the next tile row)
+                        const f32x2 m0 = {acc[0][j][r], acc[0][j][r + 1]}, m1 = {acc[1][j][r], acc[1][j][r + 1]};
+                        const f32x2 m2 = {acc[2][j][r], acc[2][j][r + 1]}, m3 = {acc[3][j][r], acc[3][j][r + 1]};
+                        const f32x2 s0 = m0 + m1 + m2, s1 = m1 - m2 - m3;
+                        sb[trow * PC_KB + j * 32] = s0[0];
+                        sb[(trow + 1) * PC_KB + j * 32] = s0[1];
+                        sb[WG_TILES * PC_KB + trow * PC_KB + j * 32] = s1[0];
+                        sb[WG_TILES * PC_KB + (trow + 1) * PC_KB + j * 32] = s1[1];
                     }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -545,37 +559,53 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[q][j][r] = 0.f;
             }
+            if (PC_DBG(64) && blockIdx.x == 0 && wave == 0 && lane == 0 && t < 64) p.tdbg[t * 8 + 0] = __builtin_readcyclecounter();
             __syncthreads();
+            if (PC_DBG(64) && blockIdx.x == 0 && wave == 0 && lane == 0 && t < 64) p.tdbg[t * 8 + 1] = __builtin_readcyclecounter();
             it_cur = it_nxt;
             ck_cur = ck_nxt;
         }
     } else {
-        int it_cur = (int)blockIdx.x, ck_cur = 0;  // chunk step t (what the multipliers are on)
-        int it_ld = it_cur, ck_ld = 0;             // the chunk step whose patch loads were issued last
-        auto next_load = [&](f32x2 (&raw)[16]) __attribute__((always_inline)) {
-            if (++ck_ld == nchunks) { ck_ld = 0; it_ld += G; setup_item(it_ld); }
-            load_patch(ck_ld, raw);
+        if (PC_DBG(32)) __builtin_amdgcn_s_setprio(2);
+        int it_cur = (int)blockIdx.x, ck_cur = 0;  // chunk step s (what the multipliers are on)
+        int it_ld = it_cur, ck_ld = pair;          // the chunk step whose patch loads were issued last (this wave: s = pair mod 2)
+        auto next_load = [&]() __attribute__((always_inline)) {
+            ck_ld += 2;
+            if (ck_ld >= nchunks) { ck_ld -= nchunks; it_ld += G; setup_item(it_ld); }
+            load_patch(ck_ld);
         };
-        setup_item(it_cur);
-        load_patch(0, rawB);
-        if (T > 1) next_load(rawA);
-        transform_store(0, rawB);
+        setup_item(it_ld);
+        load_patch(ck_ld);
+        stage_a();
+        if (pair + 2 < T) next_load();
+        if (pair == 0) stage_b(0);
         __syncthreads();
-        // step t: rcur holds the patch of chunk step t + 1, rnext is free for the loads of step t + 2
-        auto step = [&](int t, const f32x2 (&rcur)[16], f32x2 (&rnext)[16]) __attribute__((always_inline)) {
-            if (t + 2 < T) next_load(rnext);
-            if (t + 1 < T) transform_store((t + 1) & 1, rcur);
-            // the item the multipliers finished one step ago (in one piece: spreading the passes over the item's steps,
-            // and giving the stores waves of their own, were both measured slower)
-            if (ck_cur == 0 && t > 0) epilogue(it_cur - G, 0, 8);
+        for (int s = 0; s < T; ++s) {
+            if ((s & 1) == pair) {  // stage A of chunk step s + 2 (its patch is in raw), then the loads of step s + 4
+                if (s + 2 < T) {
+                    stage_a();
+                    if (s + 4 < T) next_load();
+                }
+            } else if (s + 1 < T) {
+                stage_b((s + 1) & 1);  // chunk step s + 1: the image the multipliers read after the barrier below
+            }
+            // output transform of the item the multipliers finished one step ago: its two halves in the first two steps of
+            // this item (S is next written at the end of this item's last step)
+            if (it_cur != (int)blockIdx.x) {
+                if (nchunks >= 3) {
+                    if (ck_cur < 2) epilogue(it_cur - G, ck_cur);
+                } else if (ck_cur == 0) {
+                    epilogue(it_cur - G, 0);
+                    epilogue(it_cur - G, 1);
+                }
+            }
+            if (PC_DBG(64) && blockIdx.x == 0 && wave == 4 && lane == 0 && s < 64) p.tdbg[s * 8 + 2] = __builtin_readcyclecounter();
             __syncthreads();
+            if (PC_DBG(64) && blockIdx.x == 0 && wave == 4 && lane == 0 && s < 64) p.tdbg[s * 8 + 3] = __builtin_readcyclecounter();
             if (++ck_cur == nchunks) { ck_cur = 0; it_cur += G; }
-        };
-        for (int t = 0; t < T; t += 2) {
-            step(t, rawA, rawB);
-            if (t + 1 < T) step(t + 1, rawB, rawA);
         }
-        epilogue(it_cur - G, 0, 8);
+        epilogue(it_cur - G, 0);
+        epilogue(it_cur - G, 1);
     }
 }
 
@@ -833,7 +863,7 @@ static bool pc_set_lds() {
 #define PC_ATTR(D) ok = ok && hipFuncSetAttribute((const void*)winograd_pc_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS_BYTES) == hipSuccess;
     PC_ATTR(0)
 #ifdef DS6G_WINO_ABLATE
-    PC_ATTR(1) PC_ATTR(2) PC_ATTR(3) PC_ATTR(4) PC_ATTR(7) PC_ATTR(8) PC_ATTR(16) PC_ATTR(24) PC_ATTR(9) PC_ATTR(10) PC_ATTR(18) PC_ATTR(17) PC_ATTR(19) PC_ATTR(32)
+    PC_ATTR(1) PC_ATTR(2) PC_ATTR(3) PC_ATTR(4) PC_ATTR(7) PC_ATTR(8) PC_ATTR(16) PC_ATTR(24) PC_ATTR(9) PC_ATTR(10) PC_ATTR(18) PC_ATTR(17) PC_ATTR(19) PC_ATTR(32) PC_ATTR(64) PC_ATTR(80) PC_ATTR(96)
 #endif
 #undef PC_ATTR
     return ok;
@@ -869,13 +899,34 @@ static int wino_fwd_launch(const float* x, const float* u, float* y, int N, int 
     void* rec = ds6g_prof_open(20000, 2.0 * N * H * W * (double)K * 9.0 * C, (hipStream_t)stream);
     if (use_pc && K % PC_KB == 0 && C >= 2 * WG_CH) {
         p.items = row_blocks * p.col_blocks * (K / PC_KB);
+        p.btw_shift = __builtin_ctz((unsigned)p.BTW);
+        p.th_magic = (unsigned)(((1ull << 32) + (unsigned)p.TH - 1) / (unsigned)p.TH);
         const int grid = p.items < n_cu ? p.items : n_cu;
 #ifdef DS6G_WINO_ABLATE
+        static unsigned long long* tdbg = nullptr;
+        if ((p.dbg & 64) && !tdbg) { (void)hipMalloc(&tdbg, 64 * 8 * 8); }
+        p.tdbg = tdbg;
         switch (p.dbg) {
 #define PC_CASE(D) case D: hipLaunchKernelGGL(winograd_pc_kernel<D>, dim3((unsigned)grid), dim3(512), PC_LDS_BYTES, (hipStream_t)stream, p); break;
-            PC_CASE(1) PC_CASE(2) PC_CASE(3) PC_CASE(4) PC_CASE(7) PC_CASE(8) PC_CASE(16) PC_CASE(24) PC_CASE(9) PC_CASE(10) PC_CASE(18) PC_CASE(17) PC_CASE(19) PC_CASE(32)
+            PC_CASE(1) PC_CASE(2) PC_CASE(3) PC_CASE(4) PC_CASE(7) PC_CASE(8) PC_CASE(16) PC_CASE(24) PC_CASE(9) PC_CASE(10) PC_CASE(18) PC_CASE(17) PC_CASE(19) PC_CASE(32) PC_CASE(64) PC_CASE(80) PC_CASE(96)
 #undef PC_CASE
             default: hipLaunchKernelGGL(winograd_pc_kernel<0>, dim3((unsigned)grid), dim3(512), PC_LDS_BYTES, (hipStream_t)stream, p);
+        }
+        if (p.dbg & 64) {
+            static int shown = 0;
+            if (shown++ % 64 == 3) {  // a warm launch of each shape when the caller loops a few dozen times
+                unsigned long long h[64 * 8];
+                (void)hipDeviceSynchronize();
+                (void)hipMemcpy(h, tdbg, sizeof(h), hipMemcpyDeviceToHost);
+                const int T = ((p.items + grid - 1) / grid) * (C / WG_CH);
+                fprintf(stderr, "pc steps (C=%d K=%d H=%d), cycles\n", C, K, H);
+                for (int t = 1; t < T && t < 64; ++t) {
+                    const long long m0 = (long long)h[(t - 1) * 8 + 3];  // mover left the previous barrier
+                    fprintf(stderr, "  %2d: step %6lld | mult work %6lld wait %6lld | mover work %6lld wait %6lld\n", t,
+                            (long long)(h[t * 8 + 1] - h[(t - 1) * 8 + 1]), (long long)(h[t * 8 + 0] - h[(t - 1) * 8 + 1]),
+                            (long long)(h[t * 8 + 1] - h[t * 8 + 0]), (long long)h[t * 8 + 2] - m0, (long long)(h[t * 8 + 3] - h[t * 8 + 2]));
+                }
+            }
         }
 #else
         hipLaunchKernelGGL(winograd_pc_kernel<0>, dim3((unsigned)grid), dim3(512), PC_LDS_BYTES, (hipStream_t)stream, p);

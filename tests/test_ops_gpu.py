@@ -569,7 +569,11 @@ def test_cabi_error_behaviour(dev):
     close(yg.cpu().permute(0, 3, 1, 2), ref, 1e-4, 1e-5)
 
 
-@pytest.mark.parametrize("N,H,W,C,K", [(2, 8, 16, 32, 32), (3, 16, 16, 64, 64), (5, 8, 8, 128, 32), (1, 64, 64, 32, 96)])
+@pytest.mark.parametrize("N,H,W,C,K", [(2, 8, 16, 32, 32), (3, 16, 16, 64, 64), (5, 8, 8, 128, 32), (1, 64, 64, 32, 96),
+                                       # the persistent producer / consumer kernel (K % 64 == 0): 3 chunks per item, a tile-row
+                                       # block that runs past the batch, two output-channel blocks; TH = 3 (division by
+                                       # multiplication), 1x1 tile images
+                                       (7, 4, 4, 48, 128), (2, 6, 16, 64, 192), (9, 2, 2, 32, 64)])
 def test_winograd_conv3x3(dev, N, H, W, C, K):
     """Winograd F(2x2, 3x3) forward and data gradient (the same kernel on the channel-swapped, rotated filter, also
     accumulating) against torch: exact-fp32 products, only the transform arithmetic differs -> 2e-5 of the largest value."""
@@ -587,6 +591,8 @@ def test_winograd_conv3x3(dev, N, H, W, C, K):
     yg = ops.conv3x3_winograd(xg, u, K)
     close(yg.cpu().permute(0, 3, 1, 2), y.detach(), 2e-5, 2e-5)
     dyg = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    if C % 32:
+        return  # forward-only case (the data gradient has C output channels: multiples of 32)
     assert ops.winograd_ok(dyg.shape, C)
     ud = ops.winograd_weights(wg.data_ptr(), K, C, dev, dgrad=True)
     base = torch.randn(N, H, W, C, generator=g).cuda()
