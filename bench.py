@@ -114,8 +114,8 @@ def variant_name(v, dtype="f32", short=False):
         return (f"bf16-stored/{MODE_NAMES[mode]}/{t}" + ("/bf16-out" if o16 else "")) if short else \
             f"bgemm_kernel<{mode}, {t.split('x')[0]}, {t.split('x')[1]}, {o16}, *>"
     if v >= 20000:  # winograd.hip (flops recorded = those of the direct 3x3 conv it replaces)
-        return ("winograd_fwd_kernel<1>", "winograd_wgrad_kernel")[v - 20000] if not short else \
-            ("winograd/fwd+dgrad", "winograd/wgrad")[v - 20000]
+        return ("winograd_fwd_kernel<1>", "winograd_wgrad_kernel", "winograd_pc_kernel<0>")[v - 20000] if not short else \
+            ("winograd/fwd+dgrad", "winograd/wgrad", "winograd/fwd+dgrad (producer-consumer)")[v - 20000]
     bfm = ("f32", "bf16", "f32x3", "f32x6").index(dtype)
     wide, epi, walk, mode, tile = v // 10000, v % 10000 // 1000, v % 1000 // 100, v % 100 // 10, v % 10
     bm, bn = VARIANT_NAMES[tile].split("x")

@@ -32,6 +32,7 @@
         }                                                                                      \
     } while (0)
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifdef __HIPCC__

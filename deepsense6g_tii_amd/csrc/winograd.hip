@@ -104,7 +104,6 @@ __global__ __launch_bounds__(256) void winograd_weights_kernel(const float* __re
     }
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // TNK = 32-channel output blocks per workgroup.  TNK = 2 (one wave per SIMD, 64 MFMAs per wave and chunk) gives the
 // register prefetch of the next chunk twice the time to land and halves the redundant input transforms.
@@ -895,8 +894,9 @@ static int wino_fwd_launch(const float* x, const float* u, float* y, int N, int 
             return DS6G_ERR_LAUNCH;
         n_cu = prop.multiProcessorCount;
     }
-    // profiler variant 20000: forward / data gradient; flops = those of the direct 3x3 convolution it replaces
-    void* rec = ds6g_prof_open(20000, 2.0 * N * H * W * (double)K * 9.0 * C, (hipStream_t)stream);
+    // profiler variant 20000 (20002: the producer / consumer kernel): forward / data gradient; flops = those of the direct
+    // 3x3 convolution it replaces
+    void* rec = ds6g_prof_open(use_pc ? 20002 : 20000, 2.0 * N * H * W * (double)K * 9.0 * C, (hipStream_t)stream);
     if (use_pc && K % PC_KB == 0 && C >= 2 * WG_CH) {
         p.items = row_blocks * p.col_blocks * (K / PC_KB);
         p.btw_shift = __builtin_ctz((unsigned)p.BTW);

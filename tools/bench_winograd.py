@@ -11,6 +11,7 @@ L = lib()
 L.set_debug_flags(int(os.environ.get('DBG', '0')))
 st = torch.cuda.current_stream().cuda_stream
 reps = int(os.environ.get("REPS", "20"))
+ACC = 0  # timing runs: y += conv (the data-gradient form) when ACC=1 in the environment
 
 
 def timeit(fn):
@@ -31,8 +32,9 @@ for name, N, H, C, K in (("l1 64x64 c64", 60, 64, 64, 64), ("l2 32x32 c128", 60,
     u = torch.empty(L.winograd_weight_floats(K, C), device=dev)
     y = torch.empty(N, H, H, K, device=dev)
     def wino(with_u=False):
+        global ACC
         if with_u: L.winograd_weights(w.data_ptr(), u.data_ptr(), K, C, 0, st)
-        L.conv3x3_winograd_fwd(x.data_ptr(), u.data_ptr(), y.data_ptr(), N, H, H, C, K, 0, st)
+        L.conv3x3_winograd_fwd(x.data_ptr(), u.data_ptr(), y.data_ptr(), N, H, H, C, K, ACC, st)
     L.winograd_weights(w.data_ptr(), u.data_ptr(), K, C, 0, st)
     wino()
     ref = ops.conv2d_fwd(x, w.data_ptr(), K, 3, 3, 1, 1)
@@ -49,6 +51,7 @@ for name, N, H, C, K in (("l1 64x64 c64", 60, 64, 64, 64), ("l2 32x32 c128", 60,
     dref = ops.conv2d_dgrad(dy, w.data_ptr(), (N, H, H, C), 3, 3, 1, 1)
     derr = ((dx - dref).abs().max() / dref.abs().max()).item()
     td = timeit(lambda: ops.conv2d_fwd(x, w.data_ptr(), K, 3, 3, 1, 1, out=ref))
+    ACC = int(os.environ.get("ACC", "0"))
     tw = timeit(lambda: wino(False))
     twu = timeit(lambda: wino(True))
     print(f"{name:22s} {td:10.1f} {tw:9.1f} {twu:10.1f} {err:12.2e}  dgrad err {derr:.2e}", flush=True)
