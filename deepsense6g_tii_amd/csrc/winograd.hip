@@ -311,12 +311,18 @@ __global__ __launch_bounds__(256, (TNK == 1 ? 2 : 1)) void winograd_fwd_kernel(c
 // Producer / consumer form of the forward kernel (the default when K % 64 == 0): the same arithmetic, but the two
 // halves of the chunk loop no longer share a wave.  One PERSISTENT workgroup of 8 waves per CU walks a list of work
 // items (32 tiles x 64 output channels each); waves 0-3 (one per SIMD) only multiply - wave w owns the position row
-// 4w..4w+3 x two 32-channel blocks, 64 MFMAs per 16-channel chunk, its U fragments refilled in place one chunk ahead
-// right after the MFMAs that read them - and waves 4-7 only move data: patch loads one chunk ahead, B^T d B, the V image
-// of the NEXT chunk (double-buffered), and the output transform + stores of the PREVIOUS item while the multipliers
-// are already in the next one.  One barrier per chunk; the chunk sequence runs across item boundaries, so prologue and
-// output transform are paid once per workgroup, not once per item.  The multipliers fold the column half of A^T M A
-// in registers (their four positions are one row of the 4x4 grid), which halves the LDS hand-over image.
+// 4w..4w+3 x two 32-channel blocks, 64 MFMAs per 16-channel chunk step, its U fragments refilled in place one step ahead
+// right after the MFMAs that read them - and waves 4-7 only move data: patch loads two steps ahead, B^T d B in two
+// half-steps, the V image of the NEXT step (double-buffered), and the output transform + stores of the PREVIOUS item
+// while the multipliers are already in the next one.  One barrier per chunk step; the step sequence runs across item
+// boundaries, so prologue and output transform are paid once per workgroup, not once per item.  The multipliers fold the
+// column half of A^T M A in registers (their four positions are one row of the 4x4 grid), which halves the LDS hand-over
+// image.  What bounds it (per-step clocks of workgroup 0, DS6G_WINO_DBG=64 in a -DDS6G_WINO_ABLATE build): a steady step
+// is 5000-5200 cycles for 4096 cycles of MFMA - beside the MFMA stream every other vector instruction of the SIMD
+// (24 of the multiplier, 48 of the mover per step) costs time: about 13 cycles in the multiplier's own stream, a whole
+// MFMA slot in its partner's (tools/mfma_valu_coexec.hip) - plus 2-4 thousand cycles at each item boundary (S hand-over,
+// output transform, patch offsets of the next item).  The same split was built for the weight-gradient kernel and
+// measured slower (160 / 131 / 132 us against 125 / 103 / 104): its movers need 120-220 vector instructions per 64 MFMAs.
 #define PC_DBG(bit) ((DBG & (bit)) != 0)  // compile-time ablations (a -DDS6G_WINO_ABLATE build instantiates them)
 constexpr int PC_KB = 64;                                     // output channels per item
 constexpr int PC_V_FLOATS = 2 * 16 * WG_TILES * WG_CH;        // two V images            (64 KiB)
