@@ -35,6 +35,16 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// a - b on a float vector as packed FMAs: hipcc lowers a vector subtraction to one v_sub_f32 per element, while
+// fma(b, -1, a) - the same single rounding - becomes v_pk_fma_f32 (two elements per instruction).  Beside an MFMA stream every
+// vector instruction costs matrix-pipe time, so the transform code uses this for its differences.
+template <typename V>
+__device__ __forceinline__ V vsub(V a, V b) {
+    float neg1 = -1.f;
+    asm("" : "+s"(neg1));  // opaque, or instcombine folds fma(b, -1, a) back into a subtraction
+    return __builtin_elementwise_fma(b, (V)neg1, a);
+}
 #ifdef __HIPCC__
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #endif

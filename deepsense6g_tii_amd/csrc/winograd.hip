@@ -193,17 +193,17 @@ __global__ __launch_bounds__(256, (TNK == 1 ? 2 : 1)) void winograd_fwd_kernel(c
         f32x2 t[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            t[0][j] = raw[0 * 4 + j] - raw[2 * 4 + j];
+            t[0][j] = vsub(raw[0 * 4 + j], raw[2 * 4 + j]);
             t[1][j] = raw[1 * 4 + j] + raw[2 * 4 + j];
-            t[2][j] = raw[2 * 4 + j] - raw[1 * 4 + j];
-            t[3][j] = raw[1 * 4 + j] - raw[3 * 4 + j];
+            t[2][j] = vsub(raw[2 * 4 + j], raw[1 * 4 + j]);
+            t[3][j] = vsub(raw[1 * 4 + j], raw[3 * 4 + j]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const f32x2 v0 = t[i][0] - t[i][2];
+            const f32x2 v0 = vsub(t[i][0], t[i][2]);
             const f32x2 v1 = t[i][1] + t[i][2];
-            const f32x2 v2 = t[i][2] - t[i][1];
-            const f32x2 v3 = t[i][1] - t[i][3];
+            const f32x2 v2 = vsub(t[i][2], t[i][1]);
+            const f32x2 v3 = vsub(t[i][1], t[i][3]);
             float* base = lds + vb * (16 * 512) + ((i * 4) * 2048 + vdst) / 4;
             *reinterpret_cast<f32x2*>(base) = v0;
             *reinterpret_cast<f32x2*>(base + 512) = v1;
@@ -413,10 +413,10 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
         if (PC_DBG(4)) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            tc[0 * 4 + j] = raw[0 * 4 + j] - raw[2 * 4 + j];
+            tc[0 * 4 + j] = vsub(raw[0 * 4 + j], raw[2 * 4 + j]);
             tc[1 * 4 + j] = raw[1 * 4 + j] + raw[2 * 4 + j];
-            tc[2 * 4 + j] = raw[2 * 4 + j] - raw[1 * 4 + j];
-            tc[3 * 4 + j] = raw[1 * 4 + j] - raw[3 * 4 + j];
+            tc[2 * 4 + j] = vsub(raw[2 * 4 + j], raw[1 * 4 + j]);
+            tc[3 * 4 + j] = vsub(raw[1 * 4 + j], raw[3 * 4 + j]);
         }
     };
     auto stage_b = [&](int vb) __attribute__((always_inline)) {
@@ -424,10 +424,10 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float* base = Vl + vb * (16 * 512) + ((i * 4) * 2048 + vdst) / 4;
-            *reinterpret_cast<f32x4*>(base) = tc[i * 4 + 0] - tc[i * 4 + 2];
+            *reinterpret_cast<f32x4*>(base) = vsub(tc[i * 4 + 0], tc[i * 4 + 2]);
             *reinterpret_cast<f32x4*>(base + 512) = tc[i * 4 + 1] + tc[i * 4 + 2];
-            *reinterpret_cast<f32x4*>(base + 1024) = tc[i * 4 + 2] - tc[i * 4 + 1];
-            *reinterpret_cast<f32x4*>(base + 1536) = tc[i * 4 + 1] - tc[i * 4 + 3];
+            *reinterpret_cast<f32x4*>(base + 1024) = vsub(tc[i * 4 + 2], tc[i * 4 + 1]);
+            *reinterpret_cast<f32x4*>(base + 1536) = vsub(tc[i * 4 + 1], tc[i * 4 + 3]);
         }
     };
     // y = A^T S of a finished item, half e (16 tiles) of it: thread = (tile, 4 output channels), 16-byte S reads and stores
@@ -463,8 +463,8 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
         f32x4 y[4];
         y[0] = s[0][0] + s[1][0] + s[2][0];
         y[1] = s[0][1] + s[1][1] + s[2][1];
-        y[2] = s[1][0] - s[2][0] - s[3][0];
-        y[3] = s[1][1] - s[2][1] - s[3][1];
+        y[2] = vsub(vsub(s[1][0], s[2][0]), s[3][0]);
+        y[3] = vsub(vsub(s[1][1], s[2][1]), s[3][1]);
         if (p.accumulate) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) y[i] += old[i];
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
                         const int trow = (r & 3) + 8 * (r >> 2);  // + 4 * khalf = tile (r + 1: the next tile row)
                         const f32x2 m0 = {acc[0][j][r], acc[0][j][r + 1]}, m1 = {acc[1][j][r], acc[1][j][r + 1]};
                         const f32x2 m2 = {acc[2][j][r], acc[2][j][r + 1]}, m3 = {acc[3][j][r], acc[3][j][r + 1]};
-                        const f32x2 s0 = m0 + m1 + m2, s1 = m1 - m2 - m3;
+                        const f32x2 s0 = m0 + m1 + m2, s1 = vsub(vsub(m1, m2), m3);
                         sb[trow * PC_KB + j * 32] = s0[0];
                         sb[(trow + 1) * PC_KB + j * 32] = s0[1];
                         sb[WG_TILES * PC_KB + trow * PC_KB + j * 32] = s1[0];
@@ -713,17 +713,17 @@ __global__ __launch_bounds__(256, 2) void winograd_wgrad_kernel(const WinoWgradP
         for (int b = 0; b < 4; ++b) t[b] = xr[b] + sb * xr[4 + b];
         f32x4* vd = reinterpret_cast<f32x4*>(&Vs[buf][0][tt][qd * 4]);
         constexpr int PS = WW_T * WW_CB / 4;  // f32x4 stride between positions j
-        vd[0] = t[0] - t[2];
+        vd[0] = vsub(t[0], t[2]);
         vd[PS] = t[1] + t[2];
-        vd[2 * PS] = t[2] - t[1];
-        vd[3 * PS] = t[1] - t[3];
+        vd[2 * PS] = vsub(t[2], t[1]);
+        vd[3 * PS] = vsub(t[1], t[3]);
         const f32x4 e0 = ya * yr[0] + yb * yr[2], e1 = ya * yr[1] + yb * yr[3];
         f32x4* ed = reinterpret_cast<f32x4*>(&Es[buf][0][tt][qd * 4]);
         constexpr int QS = WW_T * WW_KB / 4;
         ed[0] = e0;
         ed[QS] = e0 + e1;
-        ed[2 * QS] = e0 - e1;
-        ed[3 * QS] = -e1;
+        ed[2 * QS] = vsub(e0, e1);
+        ed[3 * QS] = e1 * -1.f;
     };
 
     f32x16 acc[2][2];
