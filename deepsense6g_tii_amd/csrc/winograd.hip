@@ -907,7 +907,12 @@ static int wino_fwd_launch(const float* x, const float* u, float* y, int N, int 
         p.items = row_blocks * p.col_blocks * (K / PC_KB);
         p.btw_shift = __builtin_ctz((unsigned)p.BTW);
         p.th_magic = (unsigned)(((1ull << 32) + (unsigned)p.TH - 1) / (unsigned)p.TH);
-        const int grid = p.items < n_cu ? p.items : n_cu;
+        // one persistent workgroup per CU.  DS6G_PC_CU_RESERVE=n leaves n CUs out: a workgroup needs a whole CU (all its
+        // VGPRs, 128 KiB of LDS), so when other resident kernels (RCCL channels under data parallelism) hold a few CUs, a
+        // full-size grid would run its last workgroups in a second round
+        static const int reserve = [] { const char* e = getenv("DS6G_PC_CU_RESERVE"); return e ? atoi(e) : 0; }();
+        const int cus = n_cu - reserve > 1 ? n_cu - reserve : 1;
+        const int grid = p.items < cus ? p.items : cus;
 #ifdef DS6G_WINO_ABLATE
         static unsigned long long* tdbg = nullptr;
         if ((p.dbg & 64) && !tdbg) { (void)hipMalloc(&tdbg, 64 * 8 * 8); }
