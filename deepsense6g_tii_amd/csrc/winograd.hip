@@ -430,47 +430,83 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
             *reinterpret_cast<f32x4*>(base + 1536) = vsub(tc[i * 4 + 1], tc[i * 4 + 3]);
         }
     };
-    // y = A^T S of a finished item, half e (16 tiles) of it: thread = (tile, 4 output channels), 16-byte S reads and stores
-    auto epilogue = [&](int item, int e) __attribute__((always_inline)) {
-        if (PC_DBG(16)) return;
+    // y = A^T S of a finished item, half e (16 tiles) of it: thread = (tile, 4 output channels), 16-byte S reads and stores.
+    // Two forms that share no control flow: the PLAIN one (forward in training) issues no load at all, so nothing in it waits on
+    // the memory counter behind the patch prefetch; the FANCY one (accumulating data gradient; bias / ReLU / residual of the
+    // inference path) reads what it adds (epi_issue) and then finishes (epi_finish).
+    const bool fancy = p.accumulate || p.bias || p.residual || p.relu;
+    f32x4 old[4];  // fancy: the values read by epi_issue for the half that epi_finish stores next
+    auto epi_where = [&](int item, int eh, bool& ok, size_t& oi) __attribute__((always_inline)) {
         const int kb = item % kblocks;
         const int wg = item / kblocks;
         const int cb = wg % p.col_blocks, rb = wg / p.col_blocks;
-        const int kq = lane & 15;
-        const int tile = e * 16 + mw * 4 + (lane >> 4);
+        const int tile = eh * 16 + mw * 4 + (lane >> 4);
         const int orow = rb * p.BTH + (tile >> p.btw_shift), ocol = cb * p.BTW + (tile & (p.BTW - 1));
-        const bool ok = orow < p.rows_total;
+        ok = orow < p.rows_total;
         const int on = p.TH == 1 ? orow : (int)__umulhi((unsigned)orow, p.th_magic), oth = orow - on * p.TH;
-        const size_t oi = ((size_t)(on * p.H + 2 * oth) * p.W + 2 * ocol) * p.K + (size_t)(kb * PC_KB + kq * 4);
+        oi = ((size_t)(on * p.H + 2 * oth) * p.W + 2 * ocol) * p.K + (size_t)(kb * PC_KB + (lane & 15) * 4);
+    };
+    auto epi_y = [&](int eh, f32x4 (&y)[4]) __attribute__((always_inline)) {
+        const int tile = eh * 16 + mw * 4 + (lane >> 4);
+        f32x4 s[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                s[r][c] = *reinterpret_cast<const f32x4*>(Sl + ((r * 2 + c) * WG_TILES + tile) * PC_KB + (lane & 15) * 4);
+        y[0] = s[0][0] + s[1][0] + s[2][0];
+        y[1] = s[0][1] + s[1][1] + s[2][1];
+        y[2] = vsub(vsub(s[1][0], s[2][0]), s[3][0]);
+        y[3] = vsub(vsub(s[1][1], s[2][1]), s[3][1]);
+    };
+    auto epi_store = [&](bool ok, size_t oi, const f32x4 (&y)[4]) __attribute__((always_inline)) {
+        if (!ok) return;
         const size_t rowstride = (size_t)p.W * p.K;
+        float* o = p.y + oi;
+        *reinterpret_cast<f32x4*>(o) = y[0];
+        *reinterpret_cast<f32x4*>(o + p.K) = y[1];
+        *reinterpret_cast<f32x4*>(o + rowstride) = y[2];
+        *reinterpret_cast<f32x4*>(o + rowstride + p.K) = y[3];
+    };
+    auto epilogue_plain = [&](int item, int eh) __attribute__((always_inline)) {
+        if (PC_DBG(16)) return;
+        bool ok;
+        size_t oi;
+        epi_where(item, eh, ok, oi);
+        f32x4 y[4];
+        epi_y(eh, y);
+        epi_store(ok, oi, y);
+    };
+    auto epi_issue = [&](int item, int eh) __attribute__((always_inline)) {
+        if (PC_DBG(16)) return;
+        bool ok;
+        size_t oi;
+        epi_where(item, eh, ok, oi);
         const float* side = p.accumulate ? p.y : p.residual;  // what is added to the result (either or none)
-        f32x4 old[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) old[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (side && ok) {
+            const size_t rowstride = (size_t)p.W * p.K;
             const float* sp = side + oi;
             old[0] = *reinterpret_cast<const f32x4*>(sp);
             old[1] = *reinterpret_cast<const f32x4*>(sp + p.K);
             old[2] = *reinterpret_cast<const f32x4*>(sp + rowstride);
             old[3] = *reinterpret_cast<const f32x4*>(sp + rowstride + p.K);
         }
-        f32x4 s[4][2];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-                s[r][c] = *reinterpret_cast<const f32x4*>(Sl + ((r * 2 + c) * WG_TILES + tile) * PC_KB + kq * 4);
+    };
+    auto epi_finish = [&](int item, int eh) __attribute__((always_inline)) {
+        if (PC_DBG(16)) return;
+        bool ok;
+        size_t oi;
+        epi_where(item, eh, ok, oi);
         f32x4 y[4];
-        y[0] = s[0][0] + s[1][0] + s[2][0];
-        y[1] = s[0][1] + s[1][1] + s[2][1];
-        y[2] = vsub(vsub(s[1][0], s[2][0]), s[3][0]);
-        y[3] = vsub(vsub(s[1][1], s[2][1]), s[3][1]);
+        epi_y(eh, y);
         if (p.accumulate) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) y[i] += old[i];
-        } else if (p.bias || p.residual || p.relu) {
+        } else {
             f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.bias) bb = *reinterpret_cast<const f32x4*>(p.bias + kb * PC_KB + kq * 4);
+            if (p.bias) bb = *reinterpret_cast<const f32x4*>(p.bias + (item % kblocks) * PC_KB + (lane & 15) * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -482,13 +518,7 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
                     y[i][c] = v;
                 }
         }
-        if (ok) {
-            float* o = p.y + oi;
-            *reinterpret_cast<f32x4*>(o) = y[0];
-            *reinterpret_cast<f32x4*>(o + p.K) = y[1];
-            *reinterpret_cast<f32x4*>(o + rowstride) = y[2];
-            *reinterpret_cast<f32x4*>(o + rowstride + p.K) = y[3];
-        }
+        epi_store(ok, oi, y);
     };
 
     // The two roles run separate loops with the same number of barriers (T + 1), so neither holds the other's registers.
@@ -597,11 +627,25 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
             // output transform of the item the multipliers finished one step ago: its two halves in the first two steps of
             // this item (S is next written at the end of this item's last step)
             if (it_cur != (int)blockIdx.x) {
-                if (nchunks >= 3) {
-                    if (ck_cur < 2) epilogue(it_cur - G, ck_cur);
+                if (!fancy) {
+                    if (nchunks >= 3) {
+                        if (ck_cur < 2) epilogue_plain(it_cur - G, ck_cur);
+                    } else if (ck_cur == 0) {
+                        epilogue_plain(it_cur - G, 0);
+                        epilogue_plain(it_cur - G, 1);
+                    }
+                } else if (nchunks >= 3) {
+                    // (issuing the reads of half e a step before finishing it was measured slower: 119 / 92 / 81 / 83 us against
+                    // 113 / 88 / 79 / 86 for the accumulating form)
+                    if (ck_cur < 2) {
+                        epi_issue(it_cur - G, ck_cur);
+                        epi_finish(it_cur - G, ck_cur);
+                    }
                 } else if (ck_cur == 0) {
-                    epilogue(it_cur - G, 0);
-                    epilogue(it_cur - G, 1);
+                    for (int eh = 0; eh < 2; ++eh) {
+                        epi_issue(it_cur - G, eh);
+                        epi_finish(it_cur - G, eh);
+                    }
                 }
             }
             if (PC_DBG(64) && blockIdx.x == 0 && wave == 4 && lane == 0 && s < 64) p.tdbg[s * 8 + 2] = __builtin_readcyclecounter();
@@ -609,8 +653,14 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
             if (PC_DBG(64) && blockIdx.x == 0 && wave == 4 && lane == 0 && s < 64) p.tdbg[s * 8 + 3] = __builtin_readcyclecounter();
             if (++ck_cur == nchunks) { ck_cur = 0; it_cur += G; }
         }
-        epilogue(it_cur - G, 0);
-        epilogue(it_cur - G, 1);
+        for (int eh = 0; eh < 2; ++eh) {
+            if (!fancy) {
+                epilogue_plain(it_cur - G, eh);
+            } else {
+                epi_issue(it_cur - G, eh);
+                epi_finish(it_cur - G, eh);
+            }
+        }
     }
 }
 
