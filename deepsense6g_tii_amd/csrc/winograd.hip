@@ -343,7 +343,6 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
     const int my_items = (p.items - (int)blockIdx.x + G - 1) / G;
     const int T = my_items * nchunks;  // chunk steps of this workgroup
 
-    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
     const unsigned upos = (unsigned)((size_t)p.K * p.C * 4);  // bytes between positions of U
 
@@ -379,31 +378,47 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
     const int tt = (mw & 1) * 16 + (lane >> 2);      // tile of the transform item
     const int cq = lane & 3;                         // channel quad within the 16-channel chunk
     const unsigned vdst = (unsigned)(tt * 64 + ((cq ^ ((tt >> 2) & 3)) << 4));  // bytes within a position's [32][16] image
-    unsigned xoff[16];
+    // Patch addressing: the buffer descriptor starts one image row and one pixel BEFORE x, so the byte offset of patch pixel
+    // (0, 0) of any tile is non-negative; pixel (i, j) adds the wave-uniform (i W + j) C 4 in the instruction's scalar offset
+    // (not range-checked), and the per-lane part is one of 9 registers: base + [row i outside the image] + [column j outside],
+    // each "outside" being 2^30 - beyond the descriptor, so the hardware returns 0 for the padding.  Only rows 0 / 3 and
+    // columns 0 / 3 of a patch can fall outside.  (16 separately selected offsets cost twice the instructions per item.)
+    const auto xs_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) - (size_t)(p.W + 1) * p.C, 0,
+                                                            p.x_bytes + (unsigned)((p.W + 1) * p.C * 4), 0x00020000);
+    unsigned xo[3][3];  // [row class: 0, 1-2, 3][column class: 0, 1-2, 3]
     f32x4 raw[16], tc[16];
     auto setup_item = [&](int item) __attribute__((always_inline)) {
+        constexpr unsigned BAD = 0x40000000u;
         const int wg = item / kblocks;
         const int cb = wg % p.col_blocks, rb = wg / p.col_blocks;
         const int trow = rb * p.BTH + (tt >> p.btw_shift), tcol = cb * p.BTW + (tt & (p.BTW - 1));
         const bool tile_ok = trow < p.rows_total;
         const int n = p.TH == 1 ? trow : (int)__umulhi((unsigned)trow, p.th_magic);  // trow / TH
         const int th = trow - n * p.TH;
-        const int ih0 = 2 * th - 1, iw0 = 2 * tcol - 1;
-        const unsigned base = (unsigned)((((n * p.H + ih0) * p.W + iw0) * p.C + cq * 4) * 4);  // may wrap: only used when ok
-        const unsigned rowb = (unsigned)(p.W * p.C * 4), colb = (unsigned)(p.C * 4);
+        // pixel (2 th - 1, 2 tcol - 1) relative to the shifted descriptor = (2 th, 2 tcol) relative to x
+        const unsigned base = (unsigned)((((n * p.H + 2 * th) * p.W + 2 * tcol) * p.C + cq * 4) * 4);
+        const unsigned r[3] = {base + ((tile_ok && th > 0) ? 0u : BAD), base + (tile_ok ? 0u : BAD),
+                               base + ((tile_ok && th < p.TH - 1) ? 0u : BAD)};
+        const unsigned c0 = tcol > 0 ? 0u : BAD, c3 = tcol < p.TW - 1 ? 0u : BAD;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = tile_ok && (unsigned)(ih0 + i) < (unsigned)p.H && (unsigned)(iw0 + j) < (unsigned)p.W;
-                xoff[i * 4 + j] = ok ? base + (unsigned)i * rowb + (unsigned)j * colb : OOB_OFF;
-            }
+        for (int i = 0; i < 3; ++i) {
+            xo[i][0] = r[i] + c0;
+            xo[i][1] = r[i];
+            xo[i][2] = r[i] + c3;
+        }
     };
     auto load_patch = [&](int ck) __attribute__((always_inline)) {
         if (PC_DBG(1)) return;
+        // (opaque strides: the 16 scalar offsets are formed here with a few scalar adds instead of living in 16 SGPRs through
+        // the whole kernel, which spilled scalar registers into vector lanes)
+        unsigned rowb = (unsigned)(p.W * p.C * 4), colb = (unsigned)(p.C * 4);
+        asm volatile("" : "+s"(rowb), "+s"(colb));
+        const unsigned s0 = (unsigned)(ck * WG_CH * 4);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xoff[e], (unsigned)(ck * WG_CH * 4), 0);
+            const int i = e >> 2, j = e & 3;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(xs_rsrc, xo[i == 0 ? 0 : (i == 3 ? 2 : 1)][j == 0 ? 0 : (j == 3 ? 2 : 1)],
+                                                                 s0 + (unsigned)i * rowb + (unsigned)j * colb, 0);
 #pragma unroll
             for (int c = 0; c < 4; ++c) raw[e][c] = __uint_as_float(v[c]);
         }
@@ -940,7 +955,7 @@ static int wino_fwd_launch(const float* x, const float* u, float* y, int N, int 
     { const char* e = getenv("DS6G_WINO_DBG"); p.dbg = e ? atoi(e) : 0; }
     const int row_blocks = (p.rows_total + p.BTH - 1) / p.BTH;
     static const int pc_on = [] { const char* e = getenv("DS6G_WINO_PC"); return e ? atoi(e) : 1; }();
-    const bool use_pc = pc_on && K % PC_KB == 0 && C >= 2 * WG_CH;
+    const bool use_pc = pc_on && K % PC_KB == 0 && C >= 2 * WG_CH && (size_t)N * H * W * C * 4 + (size_t)(W + 1) * C * 4 < 0x40000000u;
     static int n_cu = 0;  // CUs of the device = persistent workgroups of winograd_pc_kernel
     if (use_pc && !n_cu) {
         int dev = 0;
