@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
 // in opposite orientations), and at HD = 128 attn_bwd_dv2_kernel forms dV = P^T dO without recomputing S: the whole
 // backward is the minimal 5 products instead of 7 (8 at HD = 128).
 template <int HD, int PART, int BF, int HAND = 0>
-__global__ __launch_bounds__(256, (HD <= 32 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2 : 1)))) void attn_bwd_dkv_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, (HD <= 16 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2 : 1)))) void attn_bwd_dkv_kernel(const AttnParams p) {
     constexpr bool DO_DV = PART != 2, DO_DK = PART != 1;
     ATTN_COMMON();
     __shared__ float lse_s[2][32];
