@@ -715,7 +715,11 @@ __global__ __launch_bounds__(256, 2) void winograd_wgrad_kernel(const WinoWgradP
     const int tend = min(p.tiles_total, tbeg + p.tiles_per_split);
     const int nchunks = (tend - tbeg + WW_T - 1) / WW_T;
 
-    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    // x through a descriptor that starts one image row and one pixel BEFORE x (patch pixel (0, 0) of any tile then has a
+    // non-negative offset; see winograd_pc_kernel): per lane ONE base + "row outside" + "column outside" (2^30 each), per
+    // patch pixel a wave-uniform scalar offset
+    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) - (size_t)(p.W + 1) * p.C, 0,
+                                                          p.x_bytes + (unsigned)((p.W + 1) * p.C * 4), 0x00020000);
     const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
     // rows of the 4x4 patch row i of B^T combines: t = d[ra] + sb * d[rb];  rows of the 2x2 dy tile row i of A combines
     const int ra = (ri == 0) ? 0 : (ri == 2 ? 2 : 1);
@@ -738,29 +742,35 @@ __global__ __launch_bounds__(256, 2) void winograd_wgrad_kernel(const WinoWgradP
     }
     f32x4 xr[8], yr[4];
     auto prefetch = [&]() {
+        constexpr unsigned BAD = 0x40000000u;
         const bool ok = tile < tend;
-        const int ih0 = 2 * tth - 1, iw0 = 2 * ttw - 1;
+        const int pix = (tn * p.H + 2 * tth) * p.W + 2 * ttw;  // pixel (2 tth, 2 ttw) of x and of dy
+        const unsigned xbase = (unsigned)((pix * p.C + c0 + qd * 4) * 4);
+        // patch rows 0 / 3 fall outside the image in the first / last tile row, columns 0 / 3 in the first / last tile column
+        const unsigned rbad0 = (ok && tth > 0) ? 0u : BAD, rbad12 = ok ? 0u : BAD, rbad3 = (ok && tth < p.TH - 1) ? 0u : BAD;
+        const unsigned cbad0 = ttw > 0 ? 0u : BAD, cbad3 = ttw < p.TW - 1 ? 0u : BAD;
+        unsigned rowb = (unsigned)(p.W * p.C * 4), colb = (unsigned)(p.C * 4);
+        asm volatile("" : "+s"(rowb), "+s"(colb));  // (opaque: the scalar pixel offsets are formed here, not kept in 8 SGPRs)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int ih = ih0 + (h ? rb : ra);
-            const bool rok = ok && (unsigned)ih < (unsigned)p.H;
+            const int r = h ? rb : ra;  // wave-uniform
+            const unsigned vrow = xbase + (r == 0 ? rbad0 : (r == 3 ? rbad3 : rbad12));
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const int iw = iw0 + b;
-                const unsigned off = (rok && (unsigned)iw < (unsigned)p.W)
-                                         ? (unsigned)((((tn * p.H + ih) * p.W + iw) * p.C + c0 + qd * 4) * 4) : OOB_OFF;
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0);
+                const unsigned voff = b == 0 ? vrow + cbad0 : (b == 3 ? vrow + cbad3 : vrow);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, voff, (unsigned)r * rowb + (unsigned)b * colb, 0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xr[h * 4 + b][e] = __uint_as_float(v[e]);
             }
         }
+        const unsigned ybase = ok ? (unsigned)((pix * p.K + k0 + qd * 4) * 4) : OOB_OFF;
+        unsigned yrow = (unsigned)(p.W * p.K * 4), ycol = (unsigned)(p.K * 4);
+        asm volatile("" : "+s"(yrow), "+s"(ycol));
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const unsigned off = ok ? (unsigned)((((tn * p.H + 2 * tth + a) * p.W + 2 * ttw + b) * p.K + k0 + qd * 4) * 4)
-                                        : OOB_OFF;
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, off, 0, 0);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, ybase, (unsigned)a * yrow + (unsigned)b * ycol, 0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) yr[a * 2 + b][e] = __uint_as_float(v[e]);
             }
@@ -806,7 +816,8 @@ __global__ __launch_bounds__(256, 2) void winograd_wgrad_kernel(const WinoWgradP
     __syncthreads();
     for (int ck = 0; ck < nchunks; ++ck) {
         const bool more = ck + 1 < nchunks;
-        if (more) prefetch();
+        prefetch();  // unconditional (past the split's end every lane is out of range and reads zeros): a conditional load
+                     // makes the compiler stage the 48 loaded registers through copies
         const float* Eb = &Es[ck & 1][wave][0][0];
         const float* Vb = &Vs[ck & 1][wave][0][0];
         float af[2][8], bf[2][8];
@@ -1022,8 +1033,8 @@ static int wino_fwd_launch(const float* x, const float* u, float* y, int N, int 
 // 1 if ds6g_conv3x3_winograd_wgrad supports the shape
 int ds6g_winograd_wgrad_supported(int N, int H, int W, int C, int K) {
     if (H % 2 || W % 2 || C % WW_CB || K % WW_KB || N <= 0) return 0;
-    const size_t xb = (size_t)N * H * W * C * 4, yb = (size_t)N * H * W * K * 4;
-    return xb < OOB_OFF && yb < OOB_OFF;
+    const size_t xb = (size_t)N * H * W * C * 4 + (size_t)(W + 1) * C * 4, yb = (size_t)N * H * W * K * 4;
+    return xb < 0x40000000u && yb < OOB_OFF;
 }
 
 // dw[K][3][3][C] (+)= weight gradient of the 3x3 / stride 1 / pad 1 conv from x [N][H][W][C] and dy [N][H][W][K];
