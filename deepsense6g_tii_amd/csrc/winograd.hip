@@ -988,7 +988,11 @@ static int wino_fwd_launch(const float* x, const float* u, float* y, int N, int 
         // full-size grid would run its last workgroups in a second round
         static const int reserve = [] { const char* e = getenv("DS6G_PC_CU_RESERVE"); return e ? atoi(e) : 0; }();
         const int cus = n_cu - reserve > 1 ? n_cu - reserve : 1;
-        const int grid = p.items < cus ? p.items : cus;
+        // the smallest grid that needs no more rounds than all CUs would: at the model's batch (60 frames) every layer has a
+        // multiple of 240 items, so 240 workgroups are as fast as 256 (measured: 175.5 vs 176.1 samples/s) and 16 CUs stay
+        // free for whatever else is resident
+        const int rounds = (p.items + cus - 1) / cus;
+        const int grid = (p.items + rounds - 1) / rounds;
 #ifdef DS6G_WINO_ABLATE
         static unsigned long long* tdbg = nullptr;
         if ((p.dbg & 64) && !tdbg) { (void)hipMalloc(&tdbg, 64 * 8 * 8); }
