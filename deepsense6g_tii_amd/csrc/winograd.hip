@@ -16,6 +16,7 @@
 // The next chunk's patch and U fragments are prefetched into registers while the MFMAs of the current chunk run.
 #include "common.h"
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include <cstdio>
 
@@ -950,6 +951,22 @@ static bool pc_set_lds() {
     return ok;
 }
 
+// CU count of the calling thread's current device, with the 128 KiB dynamic-LDS attribute of winograd_pc_kernel set on
+// that device - once per device and process, safe under concurrent first calls (a process may drive several devices, one
+// thread each, as torch.nn.DataParallel callers do).  -> 0 on failure.
+static int pc_device_cus() {
+    static std::mutex mu;
+    static int cus[64] = {};   // 0 = not initialised, -1 = failed
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && pc_set_lds()) ? prop.multiProcessorCount : -1;
+    }
+    return cus[dev] > 0 ? cus[dev] : 0;
+}
+
 static int wino_fwd_launch(const float* x, const float* u, float* y, int N, int H, int W, int C, int K, int accumulate,
                            const float* bias, const float* residual, int relu, void* stream) {
     WinoParams p{};
@@ -967,15 +984,9 @@ static int wino_fwd_launch(const float* x, const float* u, float* y, int N, int 
     const int row_blocks = (p.rows_total + p.BTH - 1) / p.BTH;
     static const int pc_on = [] { const char* e = getenv("DS6G_WINO_PC"); return e ? atoi(e) : 1; }();
     const bool use_pc = pc_on && K % PC_KB == 0 && C >= 2 * WG_CH && (size_t)N * H * W * C * 4 + (size_t)(W + 1) * C * 4 < 0x40000000u;
-    static int n_cu = 0;  // CUs of the device = persistent workgroups of winograd_pc_kernel
-    if (use_pc && !n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-            !pc_set_lds())
-            return DS6G_ERR_LAUNCH;
-        n_cu = prop.multiProcessorCount;
-    }
+    // CUs of the CURRENT device = persistent workgroups of winograd_pc_kernel; the LDS attribute is per device too
+    int n_cu = 0;
+    if (use_pc && (n_cu = pc_device_cus()) <= 0) return DS6G_ERR_LAUNCH;
     // profiler variant 20000 (20002: the producer / consumer kernel): forward / data gradient; flops = those of the direct
     // 3x3 convolution it replaces
     void* rec = ds6g_prof_open(use_pc ? 20002 : 20000, 2.0 * N * H * W * (double)K * 9.0 * C, (hipStream_t)stream);

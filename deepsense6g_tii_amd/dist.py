@@ -109,5 +109,5 @@ def attach(model, optimizer, group=None, min_bucket_elems=8 << 20):
     optimizer.grad_scale = 1.0 / red.world
     # independent dropout masks per rank, as DataParallel replicas draw from their own device RNG
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    model.set_dropout_seed(model._seed, rank)
+    model.set_dropout_seed(model._base_seed, rank)   # from the UNMIXED seed: attach() twice, or after a resume, mixes once
     return red

@@ -208,7 +208,8 @@ class TransFuser(nn.Module):
             self.output = nn.Linear(64, 64)
         if pretrain_weight:
             self.load_pretrained_weight()
-        self._seed = 0x5DEECE66D
+        self._seed = self._base_seed = 0x5DEECE66D
+        self._seed_rank = 0
         self._drop_counter = 0   # counter offset of the next dropout site inside the CURRENT forward (restarts at 0 every forward)
         # device-resident dropout salt: advanced by SALT_STRIDE on the device at the start of every training forward and
         # added to every mask counter by the kernels at run time (ds6g_set_dropout_salt), so the launch arguments of a step
@@ -438,13 +439,7 @@ class TransFuser(nn.Module):
         self._gmode, self._fresh, self._foreign = {}, [], []
         plist = self._plist if self._arena is not None else list(self.named_parameters())
         if self.grad_ready_hook is not None:
-            # data parallel: a bucket is all-reduced in place the moment it is final, so every gradient must be written
-            # fresh this step - accumulating into an already-reduced arena would sum the earlier steps world times over
-            bad = [n for n, p in self._plist if p.grad is not None]
-            if bad:
-                raise RuntimeError(f"data-parallel backward needs zero_grad(set_to_none=True) first; {len(bad)} parameters "
-                                   f"still hold a gradient (e.g. {bad[0]}): gradient accumulation across steps is not "
-                                   "supported with the overlapped all-reduce")
+            self._dp_check_fresh_grads()
             begin = getattr(self.grad_ready_hook, "__self__", None)
             if begin is not None and hasattr(begin, "begin"):
                 begin.begin()
@@ -476,22 +471,28 @@ class TransFuser(nn.Module):
 
     def set_dropout_seed(self, seed, rank=0):
         """Seed of the counter-based dropout masks.  Data-parallel ranks must draw independent masks (the reference's
-        DataParallel replicas each use their own device RNG): the rank is mixed in with a splitmix64 finalizer."""
+        DataParallel replicas each use their own device RNG): the rank is mixed in with a splitmix64 finalizer.  The
+        UNMIXED base seed and the rank are kept: a checkpoint carries the base seed, and loading it re-applies this
+        rank's mix (rng_state / set_rng_state) - a rank-0 checkpoint never collapses the ranks onto one mask stream."""
+        self._base_seed, self._seed_rank = int(seed) & 0xFFFFFFFFFFFFFFFF, int(rank)
         z = (int(seed) + 0x9E3779B97F4A7C15 * (int(rank) + 1)) & 0xFFFFFFFFFFFFFFFF
         z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
         z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
-        self._seed = (z ^ (z >> 31)) if rank else int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._seed = (z ^ (z >> 31)) if rank else self._base_seed
         return self._seed
 
     SALT_STRIDE = 1 << 40   # counter space of one forward (bs=32: 4e9 attention-mask elements per step)
 
     def rng_state(self):
-        """(seed, salt) of the dropout stream - saved with the optimizer state so a resumed run continues the mask
-        sequence instead of replaying it from step 0."""
-        return dict(seed=int(self._seed), counter=int(self._salt_host))
+        """(base seed, salt) of the dropout stream - saved with the optimizer state so a resumed run continues the mask
+        sequence instead of replaying it from step 0.  `seed` is the UNMIXED base seed (identical on every rank)."""
+        return dict(seed=int(self._base_seed), counter=int(self._salt_host))
 
     def set_rng_state(self, st):
-        self._seed, self._salt_host = int(st["seed"]), int(st["counter"])
+        """restores the mask counter and the base seed; the seed is re-mixed with THIS model's rank (set by
+        set_dropout_seed / dist.attach), whichever of attach() and load_state_dict() ran first"""
+        self.set_dropout_seed(int(st["seed"]), self._seed_rank)
+        self._salt_host = int(st["counter"])
         if self._salt is not None:
             self._salt.fill_(self._salt_host)
 
@@ -824,6 +825,12 @@ class TransFuser(nn.Module):
                                           accumulate=bool(a2), drop=(pr, self._seed, off_p))
         wgrad(at.proj.weight, at.proj.bias, y, dz1)
         dy = ops.bf16_linear_dgrad(dz1, self._w16(at.proj.weight), C)   # bf16: the attention backward's dO
+        # the fused [3C, C] weight-gradient block and its [3C] bias block start at key.*: only valid while the three
+        # projections' gradients are contiguous arena views with ONE accumulate flag (the fp32 path falls back to three
+        # GEMMs otherwise; the bf16-storage path has no such fallback, so it refuses instead of writing wrong slices)
+        if self._qkv_fused(at, grads=True) is None:
+            raise RuntimeError("bf16-storage backward needs key / query / value gradients in the gradient arena with one "
+                               "common state (all None or all arena views): call zero_grad(set_to_none=True) first")
         dkqv = torch.empty((dy.shape[0], 3 * C), dtype=torch.bfloat16, device=dy.device)
         ops.attention_bwd_bf16io(q, k, v, y, dy, lse, B, T, nh, self._attn_ws(B, T, nh, C), pa, self._seed, off_a,
                                  out=(dkqv[:, C:2 * C], dkqv[:, :C], dkqv[:, 2 * C:]))
@@ -910,7 +917,26 @@ class TransFuser(nn.Module):
         ctx = (s, C, T, fps, offs, pe, off_e, gps_src, blk_ctx, x, mf, rf, [f.shape for f in feats])
         return outs, xo, ctx
 
+    def _dp_check_fresh_grads(self):
+        # data parallel: a bucket is all-reduced in place the moment it is final, so every gradient must be written
+        # fresh this step - accumulating into an already-reduced arena would sum the earlier steps world times over
+        bad = [n for n, p in self._plist if p.grad is not None]
+        if bad:
+            raise RuntimeError(f"data-parallel backward needs zero_grad(set_to_none=True) first; {len(bad)} parameters "
+                               f"still hold a gradient (e.g. {bad[0]}): gradient accumulation across steps is not "
+                               "supported with the overlapped all-reduce")
+
     def _run_forward(self, images, lidars, radars, gps, record):
+        """forward walk; the thread-local dropout-salt pointer of the library is scoped to the walk (set -> launches ->
+        clear, also when a launch raises): no later launch of this thread can pick up a stale salt"""
+        if record and self.grad_ready_hook is not None:
+            self._dp_check_fresh_grads()   # before the forward advances the salt, the BN running stats and _nbt
+        try:
+            return self._run_forward_walk(images, lidars, radars, gps, record)
+        finally:
+            lib().set_dropout_salt(0)
+
+    def _run_forward_walk(self, images, lidars, radars, gps, record):
         L = lib()
         st = ops._stream()
         cfg = self.config
@@ -1006,8 +1032,6 @@ class TransFuser(nn.Module):
             gru = (logits, saved)
             logits = pred
         tape = None
-        if not record:
-            L.set_dropout_salt(0)
         if record:
             tape = (B, stem_ctx, layer_ctx, stage_ctx, (fused, h1, h2, [f.shape for f in feats], gru, feats[0].dtype), gps,
                     self._salt_cur if train else None)
@@ -1225,6 +1249,12 @@ class TransFuser(nn.Module):
         self._wg_launch(stem_wgrad, (x, dc1, dwpad))
 
     def _run_backward(self, tape, dlogits):
+        try:
+            self._run_backward_walk(tape, dlogits)
+        finally:
+            lib().set_dropout_salt(0)
+
+    def _run_backward_walk(self, tape, dlogits):
         L = lib()
         st = ops._stream()
         cfg = self.config
@@ -1294,7 +1324,6 @@ class TransFuser(nn.Module):
             self._milestone_done(2 + 2 * (4 - s))
         self._milestone_done(9)
         self._end_backward()
-        L.set_dropout_salt(0)
 
 
 class TransFuser30to5(TransFuser):

@@ -333,6 +333,8 @@ class CapturedTrainStep:
     lives in device memory - the dropout salt (TransFuser._salt, added to every mask counter at run time), the optimizer's
     step count / bias corrections / lr (FusedAdamW._dev), BatchNorm's num_batches_tracked - so a replay is bit-identical to
     the eager iteration it stands for.  step(batch) copies a new batch into the graph's static input buffers first.
+    Construction has no training side effect: the warm-up iterations it runs (allocations must exist before a capture)
+    are undone, so the first step() is step 1 of the trajectory, as in the reference's Engine.train loop.
     Single process only (the data-parallel all-reduce stays on the eager path)."""
 
     def __init__(self, model, optimizer, batch, ema=None, warmup=2):
@@ -344,14 +346,34 @@ class CapturedTrainStep:
         fronts, lidars, radars, gps, target = batch
         self.static = (clone(fronts), clone(lidars), clone(radars), gps.to(dev, F32).contiguous().clone(),
                        target.to(dev, F32).contiguous().clone())
+        if warmup < 1:
+            raise ValueError("CapturedTrainStep needs warmup >= 1: the lazy one-time allocations (trunk streams, scratch, "
+                             "the dropout salt, the bf16 shadow) must exist before the capture")
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream(dev)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):   # lazy one-time work (streams, scratch growth, bf16 shadow) outside the capture
-            for _ in range(warmup):
+        # the warm-up iterations are REAL training steps on the first batch; constructing the stepper must not train, so
+        # everything they touch is snapshotted and put back: parameters, both Adam moments, the EMA shadow, BatchNorm
+        # running statistics + num_batches_tracked, the optimizer's device scalars / step count and the dropout salt
+        with torch.cuda.stream(side):
+            snap_t = [model.flat_parameters()[0], optimizer.m, optimizer.v, optimizer._dev, model._nbt]
+            if optimizer.shadow is not None:
+                snap_t.append(optimizer.shadow)
+            if ema is not None and ema.shadow is not None and ema.shadow is not optimizer.shadow:
+                snap_t.append(ema.shadow)
+            snap_t += [b for n, b in model.named_buffers() if n.endswith(("running_mean", "running_var"))]
+            snap = [t.clone() for t in snap_t]
+            snap_host = (optimizer.step_count, model._salt_host)
+            for _ in range(warmup):   # lazy one-time work (streams, scratch growth, bf16 shadow) outside the capture
                 train_iteration(model, optimizer, self.static, ema)
+            for t, c in zip(snap_t, snap):
+                t.copy_(c)
+            optimizer.step_count, model._salt_host = snap_host
+            model._salt.fill_(model._salt_host)
+            optimizer.zero_grad(set_to_none=True)
         cur.wait_stream(side)
         torch.cuda.synchronize()
+        del snap
         optimizer.sync_lr()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):

@@ -37,12 +37,20 @@ int ds6g_profile_begin(int max_records);
 int ds6g_profile_end(int* variants, double* flops, float* ms, int cap);
 /* ablation switches for kernel timing experiments (results become wrong); 0 = normal operation */
 int ds6g_set_debug_flags(int flags);
-/* matrix-core mode of the conv / linear / attention kernels (process-wide): 0 (default) = exact fp32 MFMA, the parity
- * path; 1 = operands rounded to bf16 on the way into the matrix cores, fp32 accumulate, fp32 storage (throughput
- * configuration "bf16 forward/backward" of BASELINE.json); 2 = split bf16 ("bf16x3"): each fp32 operand a is split into
- * hi = bf16(a), lo = bf16(a - hi) and a*b is evaluated as hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32
- * accumulation - relative product error <= ~2^-16 (between fp32 and TF32), fp32 storage.  Everything else (BN, LN, softmax,
- * loss, AdamW) stays fp32.  Returns DS6G_ERR_ARG for any other mode. */
+/* matrix-core mode of the conv / linear / attention kernels (process-wide).  Everything else (BN, LN, softmax, loss,
+ * AdamW, every accumulator) stays fp32 in every mode.  Returns DS6G_ERR_ARG for any other value.
+ *   0 (default) "f32"   exact fp32 MFMA (v_mfma_f32_32x32x2_f32) - the parity path, 1e-3 bar against the reference.
+ *   1           "bf16"  the "bf16 forward/backward" throughput configuration of BASELINE.json configs[1] / [4]: the
+ *                       fp32-storage entry points round their operands to bf16 (RNE) between the LDS fragment and the
+ *                       matrix core; the host (model.py) additionally routes every conv / linear but the 4-channel
+ *                       stems, and attention, to the bf16-STORAGE entry points (ds6g_bf16_*: activations, their
+ *                       gradients and a per-step shadow of the weights are bf16 in HBM; fp32 master weights).
+ *   2           "f32x3" split bf16: each fp32 operand a = hi + lo with hi = bf16(a), lo = bf16(a - hi); a*b is
+ *                       evaluated as hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32 accumulation - relative
+ *                       product error <= ~2^-16 (between fp32 and TF32), fp32 storage.
+ *   3           "f32x6" three-way truncating split (a == hi + mid + lo exactly), the six products above 2^-24 summed
+ *                       smallest first: fp32-grade products on the bf16 matrix cores, fp32 storage; the 3x3 / stride-1
+ *                       convs keep the fp32 Winograd kernels. */
 int ds6g_set_compute_mode(int mode);
 int ds6g_get_compute_mode(void);
 

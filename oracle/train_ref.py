@@ -3,10 +3,13 @@ fusion model: sigmoid focal loss, AdamW, EMA, the cyclic-cosine LR schedule and 
 metrics.  /root/reference/train2_seq.py cannot be imported (argparse + SummaryWriter + dataset at
 import time, :61,:70,:457+) so each function restates the source text it cites.
 
-Parity status: restated from source text; known-answer tests in tests/test_oracle_train.py
-(hand-derived values).  torchvision.ops.sigmoid_focal_loss is an un-vendored
-dependency (version unpinned): restated from its published formula -> "parity unpinned" at that
-boundary.
+Parity status: `cyclic_cosine_lr`, `compute_acc`, `compute_dba_score` and `ema_update` are PINNED to outputs of the
+reference's own functions (tests/golden/train_golden.npz, made in the build container by
+tests/golden/make_golden_train.py, which `ast`-extracts and executes train2_seq.py:303-383 and scheduler.py:7-119;
+bit-equal, tests/test_oracle_cpu.py::test_*_match(es)_reference_run) on top of the hand-derived known answers there.
+`adamw_step` is pinned to torch.optim.AdamW (tests/test_oracle_cpu.py::test_adamw_and_ema_match_torch).
+torchvision.ops.sigmoid_focal_loss is an un-vendored dependency (version unpinned, not importable here): restated from
+its published formula -> "parity unpinned" at that boundary.
 """
 from __future__ import annotations
 

@@ -188,18 +188,34 @@ def test_grad_reducer_flushes_early_at_the_given_milestone():
 
 
 def test_dropout_seed_differs_per_rank_and_rng_state_roundtrips():
-    """data-parallel ranks must not share dropout masks; the (seed, counter) state is checkpointed."""
+    """data-parallel ranks must not share dropout masks; the (base seed, counter) state is checkpointed.
+    ADVICE r02: resuming a data-parallel run from rank 0's checkpoint must NOT put every rank on rank 0's mask stream -
+    the checkpoint carries the unmixed base seed, each rank re-applies its own mix, in either call order."""
     from deepsense6g_tii_amd.model import GlobalConfig, TransFuser
     m = TransFuser(GlobalConfig(n_layer=1), "cpu")
     base = m._seed
     seeds = [m.set_dropout_seed(base, r) for r in range(8)]
     assert seeds[0] == base and len(set(seeds)) == 8 and all(0 <= s < 2 ** 64 for s in seeds)
-    m.set_dropout_seed(base, 3)
-    m._salt_host = 12345 * m.SALT_STRIDE          # 12345 training forwards taken
-    st = m.rng_state()
-    m2 = TransFuser(GlobalConfig(n_layer=1), "cpu")
-    m2.set_rng_state(st)
-    assert (m2._seed, m2._salt_host) == (seeds[3], 12345 * m.SALT_STRIDE)
+    # rank 0 checkpoints after 12345 training forwards
+    m0 = TransFuser(GlobalConfig(n_layer=1), "cpu")
+    m0.set_dropout_seed(base, 0)
+    m0._salt_host = 12345 * m0.SALT_STRIDE
+    st = m0.rng_state()
+    assert st == dict(seed=base, counter=12345 * m0.SALT_STRIDE)
+    # rank 3 resumes from it: attach() (= set_dropout_seed(base_seed, rank)) before the load ...
+    m3 = TransFuser(GlobalConfig(n_layer=1), "cpu")
+    m3.set_dropout_seed(m3._base_seed, 3)
+    m3.set_rng_state(st)
+    assert (m3._seed, m3._salt_host) == (seeds[3], 12345 * m0.SALT_STRIDE)
+    # ... or after it (dist.attach mixes from the UNMIXED base seed, so mixing happens exactly once)
+    m3b = TransFuser(GlobalConfig(n_layer=1), "cpu")
+    m3b.set_rng_state(st)
+    assert m3b._seed == base
+    m3b.set_dropout_seed(m3b._base_seed, 3)
+    m3b.set_dropout_seed(m3b._base_seed, 3)          # attach() twice is harmless
+    assert (m3b._seed, m3b._salt_host) == (seeds[3], 12345 * m0.SALT_STRIDE)
+    # a rank-3 checkpoint holds the base seed too, so any rank may resume from any rank's file
+    assert m3.rng_state() == st
 
 
 def test_per_scenario_metrics_and_confidence_csv(tmp_path):
@@ -238,3 +254,27 @@ def test_bench_roofline_fraction_is_an_executed_fraction():
     assert 0.4 < roof["frac"] < 0.5 and abs(roof["achieved"] - roof["frac"] * roof["peak"]) < 1e-9
     assert roof["algorithmic_tflops"] > roof["achieved"] * 2.2
     assert roof["frac"] <= 1.0 and roof["largest_direct_kernel"]["frac"] <= 1.0
+
+
+def test_train_pieces_match_reference_run(tmp_path):
+    """The product's host-side training pieces (train.py) against outputs of the REFERENCE's own functions
+    (tests/golden/train_golden.npz <- tests/golden/make_golden_train.py: train2_seq.py:338-383, scheduler.py:82-119)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_golden.npz"))
+    for base in (1e-4, 5e-4):
+        class Opt:
+            param_groups = [dict(lr=base)]
+        sch = T.CyclicCosineDecayLR(Opt())       # stepped once per epoch, as train2_seq.py:613-615
+        for e in range(61):
+            assert sch.get_last_lr()[0] == g[f"lr_base{base:g}"][e], (base, e)
+            sch.step()
+    for i in range(4):
+        pred, true = g[f"metric{i}_pred"], g[f"metric{i}_true"]
+        assert np.array_equal(T.compute_acc(pred, true), g[f"metric{i}_acc"])
+        assert np.array_equal(T.compute_acc(pred, true, top_k=(1, 3, 5)), g[f"metric{i}_acc5"])
+        assert abs(T.compute_DBA_score(pred, true) - float(g[f"metric{i}_dba"])) < 1e-12
+        assert abs(T.compute_DBA_score(pred, true, max_k=5, delta=3) - float(g[f"metric{i}_dba_k5_d3"])) < 1e-12
+    out = tmp_path / "beam_pred.csv"
+    T.save_pred_to_csv(g["metric1_pred"], target_csv=str(out))
+    assert out.read_text() == str(g["csv_text"])            # byte-identical to the file pandas wrote for the reference
+    T.save_pred_to_csv(g["metric1_pred"], top_k=(1, 2, 3, 4, 5), target_csv=str(out))
+    assert out.read_text() == str(g["csv_text_top5"])

@@ -148,3 +148,42 @@ def test_metrics_known_answers():
     assert list(tr.compute_acc(pred, np.array([3]))) == [0.0, 100.0, 100.0]
     with pytest.raises(Exception):
         tr.compute_acc(pred, np.array([1, 2]))
+
+
+# ---- the restated training pieces against outputs of the REFERENCE's own functions (tests/golden/train_golden.npz, made
+# by tests/golden/make_golden_train.py from train2_seq.py:303-383 and scheduler.py:7-119 in the build container) ----
+TRAIN_GOLD = os.path.join(os.path.dirname(__file__), "golden", "train_golden.npz")
+
+
+def test_schedule_matches_reference_run():
+    g = np.load(TRAIN_GOLD)
+    for base in (1e-4, 5e-4):
+        ref = g[f"lr_base{base:g}"]
+        assert ref.shape == (61,)
+        for e in range(61):
+            assert tr.cyclic_cosine_lr(e, base) == ref[e], (base, e)     # same arithmetic, same order: bit-equal
+
+
+def test_metrics_match_reference_run():
+    g = np.load(TRAIN_GOLD)
+    for i in range(4):
+        pred, true = g[f"metric{i}_pred"], g[f"metric{i}_true"]
+        assert np.array_equal(tr.compute_acc(pred, true), g[f"metric{i}_acc"])
+        assert np.array_equal(tr.compute_acc(pred, true, top_k=(1, 3, 5)), g[f"metric{i}_acc5"])
+        assert tr.compute_dba_score(pred, true) == float(g[f"metric{i}_dba"])
+        assert tr.compute_dba_score(pred, true, max_k=5, delta=3) == float(g[f"metric{i}_dba_k5_d3"])
+
+
+def test_ema_matches_reference_run():
+    """EMA.register -> 5 x (perturb, update) of the reference class on a tiny module (one parameter frozen: the reference
+    skips requires_grad = False); the oracle's ema_update on the same parameter sequence must give the same shadow."""
+    g = np.load(TRAIN_GOLD)
+    steps = torch.from_numpy(g["ema_param_steps"])            # [5, 58]: all parameters after each perturbation
+    n_tracked = g["ema_shadow"].shape[0]                      # 55: the frozen bias (3 values, last) is not tracked
+    assert steps.shape == (5, 58) and n_tracked == 55 and list(g["ema_names"]) == ["0.weight", "0.bias", "2.weight"]
+    from tests.golden.make_golden_train import tiny_model
+    m = tiny_model(7)
+    shadow = torch.cat([p.detach().flatten() for p in m.parameters()])[:n_tracked].clone()     # register()
+    for s in range(5):
+        shadow = tr.ema_update(shadow, steps[s, :n_tracked], 0.999)
+    assert torch.equal(shadow, torch.from_numpy(g["ema_shadow"]))

@@ -179,17 +179,21 @@ def test_captured_train_step_is_bit_identical_to_eager(dev, mode):
             ema.register()
             losses = []
             if captured:
-                # the capture runs 2 eager warm-up iterations on batches[0] (the capture pass itself executes nothing): the
-                # other run mirrors them eagerly
+                # construction runs 2 warm-up iterations on batches[0] and UNDOES them: nothing may have moved
+                before = [t.clone() for t in (model.flat_parameters()[0], opt.m, opt.v, opt.shadow, *model.buffers())]
                 step = CapturedTrainStep(model, opt, batches[0], ema, warmup=2)
+                after = (model.flat_parameters()[0], opt.m, opt.v, opt.shadow, *model.buffers())
+                assert all(torch.equal(x, y) for x, y in zip(before, after))
+                assert opt.step_count == 0 and model._salt_host == 0 == int(model._salt.item())
+                assert all(p.grad is None for p in model.parameters())
+                with pytest.raises(ValueError):
+                    CapturedTrainStep(model, opt, batches[0], ema, warmup=0)
                 for b in batches[1:]:
                     opt.param_groups[0]["lr"] *= 0.5          # a schedule change between replays reaches the graph
                     loss, _ = step(b)
                     losses.append(float(loss))
                 assert step.steps_replayed == 2
             else:
-                for _ in range(2):
-                    train_iteration(model, opt, batches[0], ema)
                 for b in batches[1:]:
                     opt.param_groups[0]["lr"] *= 0.5
                     loss, _ = train_iteration(model, opt, b, ema)
@@ -199,7 +203,7 @@ def test_captured_train_step_is_bit_identical_to_eager(dev, mode):
                              bufs=[b.clone() for b in model.buffers()], losses=losses, steps=opt.step_count,
                              salt=(model._salt_host, int(model._salt.item()))))
         a, b = runs
-        assert a["losses"] == b["losses"] and a["steps"] == b["steps"] == 4
+        assert a["losses"] == b["losses"] and a["steps"] == b["steps"] == 2
         assert a["salt"] == b["salt"] and a["salt"][0] == a["salt"][1]
         for k in ("p", "m", "v", "sh"):
             assert torch.equal(a[k], b[k]), k
