@@ -18,6 +18,14 @@ Prints ONE JSON line on rank 0 with the contract fields plus
                  FLOPs than the direct 3x3 conv it replaces, its algorithmic rate is the separate key
                  `algorithmic_tflops`; step_frac = whole-step algorithmic rate / peak; traffic = HBM bytes per launch
                  from the committed PMC passes (profiles/r0N_pmc_traffic.json)
+  other_modes  : the same step in the other matrix-core modes, same timing protocol, never the headline: f32x3 / f32x6
+                 (split bf16, fp32 storage) and the bf16 configuration of BASELINE configs[1] - "bf16" on the full-fusion
+                 batch and "bf16_image_only" on configs[1]'s zeroed LiDAR / radar batch - each bf16 entry with step_frac
+                 against the 2.5 PFLOP/s dense bf16 peak and the roofline of its dominant bgemm_kernel instantiation
+  dba          : the second half of BASELINE's metric ("DBA top-k on held-out", train2_seq.py:363-383): a fresh model
+                 trained for 150 steps on the synthetic learnable beam task on the HIP path (tools/train_synthetic.py's
+                 protocol), held-out DBA / top-k by train.validate at steps 0 / 50 / 100 / 150, the committed CPU-oracle
+                 curve of the same protocol beside it (profiles/r02_train_synthetic_dba_cpu_oracle_150.jsonl)
   cpu_baseline : the CPU oracle (oracle/, torch fp32 on the host cores): bs=2 (3 warm-up + 10 timed) and bs=12
                  (1 warm-up + 3 timed) steps of fwd + focal + bwd + AdamW, median step time, CPU model and threads.
 """
@@ -174,7 +182,7 @@ def roofline_from_records(agg, dtype, traffic):
 def pmc_traffic_table():
     """HBM bytes per launch by kernel name from the committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and WRITE_SIZE
     are collected in separate runs of this same command, so bench.py cannot measure them live; {} when absent."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if os.path.exists(path):
             return {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(path))["kernels"].items()}
@@ -208,6 +216,60 @@ class IgemmTimer:
         return agg
 
 
+def dba_leg(dev, steps=150, batch=12, pool=16, eval_batches=4, eval_every=50):
+    """Held-out DBA / top-k of the HIP path on the synthetic learnable task: tools/train_synthetic.py's protocol (fresh
+    model from torch.manual_seed(100), training batches of seeds 100 + i, held-out seeds 10 000 + i, AdamW lr 1e-4, focal
+    loss on the soft target, dropout 0.1, train-mode BN; evaluation = train.validate: eval-mode forward -> argsort ->
+    compute_DBA_score / compute_acc, train2_seq.py:158-221, 347-383).  The CPU-oracle run of the same protocol (same init,
+    same batches, torch's own dropout stream; oracle/train_synthetic_cpu.py, 2 h on 7 threads) is read from profiles/."""
+    from deepsense6g_tii_amd.model import GlobalConfig, TransFuser
+    from deepsense6g_tii_amd.synthetic import make_batch
+    from deepsense6g_tii_amd.train import FusedAdamW, train_iteration, validate
+    t_start = time.perf_counter()
+    torch.manual_seed(100)
+    cfg = GlobalConfig()
+    model = TransFuser(cfg, dev)
+    opt = FusedAdamW(model, lr=1e-4)
+    held_out = []
+    for i in range(eval_batches):  # disjoint seed range
+        f, l, r, g, _, beam = make_batch(batch, seed=10_000 + i, device=dev, learnable=True)
+        held_out.append((f, l, r, g, beam))
+    train_pool = [make_batch(batch, seed=100 + i, device=dev, learnable=True)[:5] for i in range(pool)]
+
+    def evaluate(step, loss=None):
+        dba, acc, _ = validate(model, held_out)
+        model.train()
+        return dict(step=step, dba=dba, top123=acc.tolist(), **({} if loss is None else {"loss": float(loss)}))
+
+    curve = [evaluate(0)]
+    model.train()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for step in range(1, steps + 1):
+        loss, _ = train_iteration(model, opt, train_pool[step % pool])
+        if step % eval_every == 0 or step == steps:
+            curve.append(evaluate(step, loss))
+    torch.cuda.synchronize()
+    train_s = time.perf_counter() - t0
+    cpu_curve = None
+    path = os.path.join(ROOT, "profiles", "r02_train_synthetic_dba_cpu_oracle_150.jsonl")
+    if os.path.exists(path):
+        rows = [json.loads(line) for line in open(path) if line.strip()]
+        cpu_curve = [dict(step=r["step"], dba=r["dba"], top123=r["top123"]) for r in rows]
+    at = {r["step"]: r["dba"] for r in (cpu_curve or [])}
+    del model, opt, train_pool, held_out
+    torch.cuda.empty_cache()
+    return dict(metric="DBA (mean over k <= 3 of 1 - mean_i min_j<=k min(|pred_ij - y_i| / 5, 1)) and top-1/2/3 accuracy [%] "
+                       "on held-out synthetic sequences", value=curve[-1]["dba"], top123=curve[-1]["top123"],
+                steps=steps, held_out_samples=eval_batches * batch, train_batches=pool, batch=batch,
+                curve=curve, cpu_oracle_curve=cpu_curve, cpu_oracle_dba_at_same_step=at.get(steps),
+                cpu_oracle_source="profiles/r02_train_synthetic_dba_cpu_oracle_150.jsonl (oracle/train_synthetic_cpu.py: same "
+                                  "init / batches / protocol on the CPU oracle, torch's dropout stream)",
+                dtype="f32", data="synthetic learnable task (deepsense6g_tii_amd/synthetic.py: the beam index painted into "
+                                  "every modality and the GPS angle); no dataset offline",
+                train_seconds=train_s, total_seconds=time.perf_counter() - t_start)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,7 +278,10 @@ def main():
     ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (sequences)")
     ap.add_argument("--ema", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt-modes", action="store_true", help="skip the extra f32x3 / f32x6 timings beside the exact-fp32 value")
+    ap.add_argument("--no-alt-modes", action="store_true",
+                    help="skip the extra f32x3 / f32x6 / bf16 / bf16-image-only timings beside the exact-fp32 value")
+    ap.add_argument("--no-dba", action="store_true", help="skip the held-out DBA leg (150 training steps on the synthetic learnable task)")
+    ap.add_argument("--dba-steps", type=int, default=150)
     ap.add_argument("--dtype", choices=("f32", "bf16", "f32x3", "f32x6"), default="f32",
                     help="matrix-core mode: f32 = exact fp32 MFMA (parity path, default); bf16 = operands rounded to bf16, "
                          "fp32 accumulate/storage (BASELINE configs[1]-style throughput configuration); f32x3 = split bf16 "
@@ -314,45 +379,77 @@ def main():
         table = pmc_traffic_table()
         roof = roofline_from_records(agg, args.dtype, lambda v: table.get(variant_name(v, args.dtype)))
 
-    # ---- the split-bf16 matrix-core modes next to the exact one (same model / batch / timing protocol; reported beside
-    # `value`, never as it) ----
+    # ---- the other matrix-core modes next to the exact one (same model / timing protocol; reported beside `value`, never
+    # as it): split-bf16 on the same batch, and the bf16 configuration BASELINE configs[1] names ----
     alt = None
     if args.dtype == "f32" and not args.no_alt_modes:
         what = {"f32x3": "split-bf16 products (hi*hi + hi*lo + lo*hi, ~2^-16), fp32 accumulate and storage; "
                          "ds6g_set_compute_mode(2); Winograd off (direct implicit GEMM); tests/test_bf16_gpu.py",
                 "f32x6": "three-way bf16 split, six products (fp32-grade, ~2^-23) in the direct kernels and attention, fp32 "
-                         "Winograd kept for the 3x3/1 convs; ds6g_set_compute_mode(3); tests/test_bf16_gpu.py"}
+                         "Winograd kept for the 3x3/1 convs; ds6g_set_compute_mode(3); tests/test_bf16_gpu.py",
+                "bf16": "BASELINE configs[1] / [4] arithmetic on the full-fusion batch of configs[2]: bf16 forward / backward "
+                        "(activations, their gradients and a per-step weight shadow stored as bf16, csrc/bgemm.hip; fp32 master "
+                        "weights, statistics, accumulators, loss, AdamW); ds6g_set_compute_mode(1); parity unpinned (the "
+                        "reference has no reduced-precision path), builder-declared bars in tests/test_bf16_gpu.py",
+                "bf16_image_only": "BASELINE configs[1] literally: image-only (LiDAR / radar inputs zeroed, the reference's "
+                                   "'zerolike' missing-modality semantics), bs=12, bf16 forward / backward"}
+        zeroed = (fronts, [torch.zeros_like(t) for t in lidars], [torch.zeros_like(t) for t in radars], gps, target)
         alt = {}
-        for mode in ("f32x3", "f32x6"):
+        for mode in ("f32x3", "f32x6", "bf16", "bf16_image_only"):
+            cmode = "bf16" if mode.startswith("bf16") else mode
+            mbatch = zeroed if mode == "bf16_image_only" else batch
             try:
                 with torch.no_grad():
                     model.eval()
                     ops.set_compute_mode("f32")
-                    ref_logits = model(fronts, lidars, radars, gps).float().clone()
-                    ops.set_compute_mode(mode)
-                    m_logits = model(fronts, lidars, radars, gps).float()
+                    ref_logits = model(*mbatch[:4]).float().clone()
+                    ops.set_compute_mode(cmode)
+                    m_logits = model(*mbatch[:4]).float()
                     dev_rel = float((m_logits - ref_logits).abs().max() / ref_logits.abs().max())
                     model.train()
                 for _ in range(2):
-                    train_iteration(model, opt, batch, ema, reducer)
+                    train_iteration(model, opt, mbatch, ema, reducer)
                 sync()
                 t0 = time.perf_counter()
                 for _ in range(args.steps):
-                    train_iteration(model, opt, batch, ema, reducer)
+                    train_iteration(model, opt, mbatch, ema, reducer)
                 sync()
                 el = time.perf_counter() - t0
                 if world > 1:
                     t = torch.tensor([el], device=dev, dtype=torch.float64)
                     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
                     el = float(t.item())
-                alt[mode] = {"value": args.batch * world * args.steps / el, "unit": "samples/s",
-                             "ms_per_step": el / args.steps * 1e3, "eval_logits_max_dev_vs_f32_rel": dev_rel,
-                             "what": what[mode]}
+                v = args.batch * world * args.steps / el
+                alt[mode] = {"value": v, "unit": "samples/s", "ms_per_step": el / args.steps * 1e3, "dtype": cmode,
+                             "step_frac": v / world * 559.3e9 / 1e12 / peak_tflops_for(cmode),
+                             "eval_logits_max_dev_vs_f32_rel": dev_rel, "what": what[mode]}
+                if cmode == "bf16":   # roofline of its dominant kernel: one instrumented single-stream step in this mode
+                    t2 = IgemmTimer()
+                    t2.install()
+                    model.multi_stream = False
+                    try:
+                        train_iteration(model, opt, mbatch, ema, reducer)
+                        agg2 = t2.summary()
+                    finally:
+                        model.multi_stream = ms_flag
+                    bg = {k: a for k, a in agg2.items() if k >= 30000}     # the bf16-stored GEMM family (the stems stay igemm)
+                    if bg:
+                        r2 = roofline_from_records(bg, "bf16", lambda v: None)
+                        r2["family"] = r2.pop("igemm_family")
+                        alt[mode]["roofline"] = r2
             except Exception as e:  # an extra mode never takes the headline line down with it
                 alt[mode] = {"error": repr(e)}
             finally:
                 ops.set_compute_mode("f32")
                 model.train()
+
+    # ---- the second half of the metric: held-out DBA / top-k after a short training run on the HIP path ----
+    dba = None
+    if rank == 0 and world == 1 and not args.no_dba and args.dtype == "f32":
+        try:
+            dba = dba_leg(dev, steps=args.dba_steps)
+        except Exception as e:
+            dba = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -388,6 +485,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "other_modes": alt,
+            "dba": dba,
         }
         if cpu:
             out["gpu_over_cpu"] = value / cpu["value"]

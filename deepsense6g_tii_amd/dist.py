@@ -30,7 +30,8 @@ def init_distributed(backend=None):
     backend = os.environ.get("DS6G_DIST_BACKEND", backend)
     if "DS6G_FORCE_DEVICE" in os.environ:
         local = int(os.environ["DS6G_FORCE_DEVICE"])
-    if world > 1 and not dist.is_initialized():
+    # DS6G_DIST_FORCE_INIT=1: build the process group even for one rank (tests/nccl_worker.py: RCCL on a one-GPU box)
+    if (world > 1 or os.environ.get("DS6G_DIST_FORCE_INIT") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -62,13 +63,21 @@ class GradReducer:
         self.lo = 0
         self.hi = 0
         self.issued = []  # (lo, hi) of every bucket this step, for tests / logging
+        # test switches (tests/nccl_worker.py): force_collective runs the all-reduce through the process group even at
+        # world size 1 (a one-GPU box can then exercise ProcessGroupNCCL's stream semantics: the collective runs on RCCL's
+        # own stream, ordered after the CURRENT stream at the time of the call); probe_stream, when set, takes a copy of
+        # every bucket at issue time under exactly that ordering (an event recorded on the current stream), so a test can
+        # tell whether the slice was final - i.e. whether every producing side stream had been joined - when it was sent
+        self.force_collective = False
+        self.probe_stream = None
+        self.probes = []
 
     @property
     def world(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
     def begin(self):
-        self.works, self.issued = [], []
+        self.works, self.issued, self.probes = [], [], []
         self.lo = self.hi = 0
 
     def ready(self, k, lo, hi):
@@ -79,7 +88,13 @@ class GradReducer:
 
     def _flush(self):
         if self.hi > self.lo:
-            if self.world > 1:
+            if self.probe_stream is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self.probe_stream.wait_event(ev)
+                with torch.cuda.stream(self.probe_stream):
+                    self.probes.append(self.g[self.lo:self.hi].clone())
+            if self.world > 1 or (self.force_collective and dist.is_initialized()):
                 self.works.append(dist.all_reduce(self.g[self.lo:self.hi], op=dist.ReduceOp.SUM, group=self.group,
                                                   async_op=True))
             self.issued.append((self.lo, self.hi))

@@ -298,11 +298,23 @@ class TransFuser(nn.Module):
             return wp[0], bp[0]
         return None
 
-    def _build_arena(self):
-        dev = self.device
+    def arena_layout(self):
+        """-> (ordered [(name, param)], {name: (offset, numel)}, {milestone: end offset}, total elements) of the flat
+        parameter / gradient arenas: parameters sorted by backward-completion milestone, key|query|value grouped, every
+        segment padded to 4 elements.  Pure host arithmetic (also valid for a model constructed on "cpu", where no arena
+        is allocated): the data-parallel bucket table is a function of this layout alone."""
         named = sorted(self.named_parameters(), key=lambda kv: self._milestone(kv[0]))  # stable
         named = self._group_qkv(named)
-        total = sum((p.numel() + 3) // 4 * 4 for _, p in named)
+        pslice, milestone_end, off = {}, {}, 0
+        for name, p in named:
+            pslice[name] = (off, p.numel())
+            off += (p.numel() + 3) // 4 * 4
+            milestone_end[self._milestone(name)] = off
+        return named, pslice, milestone_end, off
+
+    def _build_arena(self):
+        dev = self.device
+        named, _, _, total = self.arena_layout()
         self._arena = torch.zeros(total, dtype=F32, device=dev)
         self._garena = torch.zeros(total, dtype=F32, device=dev)
         self._gview = {}

@@ -104,3 +104,36 @@ def test_ranks_draw_independent_dropout_masks(dev, tmp_path):
     assert ranks[0]["seed"] == ranks[0]["seed0"]                    # rank 0 keeps the single-process stream
     assert ranks[1]["seed"] != ranks[0]["seed"]
     assert torch.isfinite(ranks[0]["grad"]).all() and torch.equal(ranks[0]["grad"], ranks[1]["grad"])
+
+
+def test_rccl_process_group_orders_buckets_after_their_producers(dev, tmp_path):
+    """the gradient exchange on the REAL RCCL backend (world size 1: one GPU here), multi_stream and
+    overlap_wgrad on - see tests/nccl_worker.py for what is checked and why only ProcessGroupNCCL exercises it."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               DS6G_DIST_FORCE_INIT="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("DS6G_DIST_BACKEND", None)
+    env.pop("DS6G_FORCE_DEVICE", None)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "nccl_worker.py"), str(tmp_path)], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    try:
+        out, _ = p.communicate(timeout=600)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        raise
+    assert p.returncode == 0, out.decode(errors="replace")[-4000:]
+    r = torch.load(os.path.join(tmp_path, "nccl_rank0.pt"), weights_only=True)
+    assert r["backend"] == "nccl" and r["grad_scale"] == 1.0
+    assert r["nan_plain"] == 0 and r["nan_reduced"] == 0          # every gradient of the NaN-poisoned arena was written
+    assert r["same"]                                                # all-reduce at world 1 = identity, bit for bit
+    assert r["loss_a"] == r["loss_b"] == r["loss_c"]
+    issued, used = r["issued"], r["used"]
+    assert len(issued) >= 3 and r["n_probes"] == len(issued)
+    assert issued[0][0] == 0 and issued[-1][1] == used
+    for (lo, hi), (lo2, hi2) in zip(issued, issued[1:]):
+        assert hi == lo2 and hi > lo
+    assert all(hi in set(r["milestone_end"].values()) for _, hi in issued)
+    # every bucket was FINAL when it was handed to the process group: the probe taken under RCCL's own ordering (after the
+    # calling stream at issue time) holds the final values - no producer on a side stream was still running or unjoined
+    assert r["nan_probe"] == [0] * len(issued), r["nan_probe"]
+    assert all(r["ok_probe"]), r["ok_probe"]
+    assert r["params_finite"]

@@ -158,6 +158,75 @@ def test_data_parallel_allreduce_world2_gloo():
     assert torch.equal(b1, torch.zeros(4))
 
 
+# the bucket table of the REAL model: 78 422 528 gradients, arena in backward-completion order, milestones
+# coalesced to >= 8 M elements, everything up to the first GPT stage flushed at milestone 7
+REAL_BUCKETS = [26016704, 29901824, 17619712, 4347200, 537088]
+
+
+def _real_milestones():
+    m = TransFuser(GlobalConfig(), "cpu")
+    _, pslice, ends, total = m.arena_layout()
+    assert total == sum(p.numel() for p in m.parameters()) == 78422528      # no padding holes in the real model
+    return [ends[k] for k in range(10)], total
+
+
+def test_real_model_bucket_table_single_process():
+    ends, total = _real_milestones()
+    red = ddist.GradReducer(torch.zeros(1), min_bucket_elems=8 << 20, flush_at=7)    # attach()'s arguments
+    red.g = torch.empty(0)          # slices of an empty tensor: only the bookkeeping is exercised here
+    red.begin()
+    lo = 0
+    for k, hi in enumerate(ends):
+        red.ready(k, lo, hi)
+        lo = hi
+    red.finish()
+    assert [hi - lo for lo, hi in red.issued] == REAL_BUCKETS and red.issued[-1][1] == total
+
+
+def _dp_worker_real(rank, world, port, ends, total, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    r, w, _ = ddist.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    # small integers: the SUM over ranks is exact in fp32 whatever order gloo adds in
+    base = (torch.arange(total, dtype=torch.int32) % 251).to(torch.float32)
+    grads = base + float(rank)
+    red = ddist.GradReducer(grads, min_bucket_elems=8 << 20, flush_at=7)
+    red.begin()
+    lo = 0
+    for k, hi in enumerate(ends):       # the backward walk's milestone order
+        red.ready(k, lo, hi)
+        lo = hi
+    red.finish()
+    expect = base * world + float(world * (world - 1) // 2)
+    out[rank] = (bool(torch.equal(grads, expect)), list(red.issued), float(grads.double().sum()))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_real_model_bucket_table_allreduce_gloo(world):
+    """the gradient exchange of `bench.py --gpus 4 / 8` - the real arena size and the real bucket
+    table, world_size 4 and 8 over gloo on the CPU: every rank issues the same five buckets and ends with the exact sum."""
+    ends, total = _real_milestones()
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_dp_worker_real, args=(r, world, port, ends, total, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    sums = set()
+    for r in range(world):
+        ok, issued, total_sum = out[r]
+        assert ok, r
+        assert [hi - lo for lo, hi in issued] == REAL_BUCKETS
+        sums.add(total_sum)
+    assert len(sums) == 1
+
+
 def test_checkpoint_prefix_and_csv(tmp_path):
     sd = {"module.join.0.weight": 1, "encoder.vel_emb1.bias": 2}
     assert T.strip_module_prefix(sd) == {"join.0.weight": 1, "encoder.vel_emb1.bias": 2}
