@@ -56,6 +56,7 @@ struct WinoParams {
     int relu;               //   0 none, 1 before the residual add, 2 after it
     int accumulate;      // y += result (data gradient summed onto the gradient of the residual branch)
     int items;           // winograd_pc_kernel: work items = tile blocks x K / 64
+    int xcd_gk;          //   XCD-aware item order: the 8 XCDs form gk channel-block groups x 8 / gk tile-block groups (0: off)
     int btw_shift;       //   log2(BTW)
     unsigned th_magic;   //   ceil(2^32 / TH), TH > 1: row / TH = umulhi(row, th_magic) for row * TH < 2^32
     unsigned long long* tdbg;  // -DDS6G_WINO_ABLATE, dbg 64: per-step barrier arrive / leave clocks of workgroup 0
@@ -343,6 +344,28 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
     const int nchunks = p.C / WG_CH;
     const int my_items = (p.items - (int)blockIdx.x + G - 1) / G;
     const int T = my_items * nchunks;  // chunk steps of this workgroup
+    // Item order.  A workgroup walks item ids it0, it0 + its, it0 + 2 its, ...; id q decodes to channel block
+    // kb0 + q % kdiv and tile block tb0 + q / kdiv.  Plain order: ids = blockIdx.x + i G over all items (kb fastest).
+    // XCD-aware order (p.xcd_gk > 0; needs G % 8 == 0 and items % G == 0): the hardware deals workgroups round-robin over
+    // the 8 XCDs (workgroup w runs on XCD w & 7, each with a private 4 MB L2), so the XCDs are arranged as gk channel-block
+    // groups x gt = 8 / gk tile-block groups; an XCD owns kblocks / gk channel blocks x a CONTIGUOUS run of tile blocks and its
+    // G / 8 workgroups walk that sub-list together, 30 consecutive ids at a time: the items that share an input tile block
+    // (all its channel blocks) and the neighbouring tile blocks (overlapping 4x4 / stride-2 patches) meet in one L2 instead
+    // of being fetched by up to 8 of them, and an XCD touches only its own slice of U.  The host picks gk per layer shape
+    // (minimum of |U| gt + |x| gk).
+    int it0 = (int)blockIdx.x, its = G, kdiv = kblocks, kb0 = 0, tb0 = 0;
+    if (p.xcd_gk > 0) {
+        const int xcd = (int)blockIdx.x & 7, gk = p.xcd_gk, gt = 8 / gk;
+        kdiv = kblocks / gk;
+        kb0 = (xcd % gk) * kdiv;
+        tb0 = (xcd / gk) * ((p.items / kblocks) / gt);
+        it0 = (int)blockIdx.x >> 3;
+        its = G >> 3;
+    }
+    it0 = __builtin_amdgcn_readfirstlane(it0); its = __builtin_amdgcn_readfirstlane(its);
+    kdiv = __builtin_amdgcn_readfirstlane(kdiv); kb0 = __builtin_amdgcn_readfirstlane(kb0); tb0 = __builtin_amdgcn_readfirstlane(tb0);
+    auto item_kb = [&](int item) __attribute__((always_inline)) { return kb0 + item % kdiv; };
+    auto item_tb = [&](int item) __attribute__((always_inline)) { return tb0 + item / kdiv; };
 
     const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
     const unsigned upos = (unsigned)((size_t)p.K * p.C * 4);  // bytes between positions of U
@@ -354,7 +377,7 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
     const int swz = (l31 >> 2) & 3;
     // byte offset (scalar) of the U fragment block of (item, chunk) for position row `wave`, q = 0, j = 0
     auto u_soff = [&](int item, int ck) -> unsigned {
-        const int kb = item % kblocks;
+        const int kb = item_kb(item);
         return (unsigned)(wave * 4) * upos + (unsigned)(((kb * (PC_KB / 32)) * (p.C >> 4) + ck) * 2048);
     };
     auto load_u = [&](int q, int j, unsigned soff) {
@@ -390,7 +413,7 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
     f32x4 raw[16], tc[16];
     auto setup_item = [&](int item) __attribute__((always_inline)) {
         constexpr unsigned BAD = 0x40000000u;
-        const int wg = item / kblocks;
+        const int wg = item_tb(item);
         const int cb = wg % p.col_blocks, rb = wg / p.col_blocks;
         const int trow = rb * p.BTH + (tt >> p.btw_shift), tcol = cb * p.BTW + (tt & (p.BTW - 1));
         const bool tile_ok = trow < p.rows_total;
@@ -453,8 +476,8 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
     const bool fancy = p.accumulate || p.bias || p.residual || p.relu;
     f32x4 old[4];  // fancy: the values read by epi_issue for the half that epi_finish stores next
     auto epi_where = [&](int item, int eh, bool& ok, size_t& oi) __attribute__((always_inline)) {
-        const int kb = item % kblocks;
-        const int wg = item / kblocks;
+        const int kb = item_kb(item);
+        const int wg = item_tb(item);
         const int cb = wg % p.col_blocks, rb = wg / p.col_blocks;
         const int tile = eh * 16 + mw * 4 + (lane >> 4);
         const int orow = rb * p.BTH + (tile >> p.btw_shift), ocol = cb * p.BTW + (tile & (p.BTW - 1));
@@ -522,7 +545,7 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
             for (int i = 0; i < 4; ++i) y[i] += old[i];
         } else {
             f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.bias) bb = *reinterpret_cast<const f32x4*>(p.bias + (item % kblocks) * PC_KB + (lane & 15) * 4);
+            if (p.bias) bb = *reinterpret_cast<const f32x4*>(p.bias + item_kb(item) * PC_KB + (lane & 15) * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -539,7 +562,7 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
 
     // The two roles run separate loops with the same number of barriers (T + 1), so neither holds the other's registers.
     if (consumer) {
-        int it_cur = (int)blockIdx.x, ck_cur = 0;  // chunk step t
+        int it_cur = it0, ck_cur = 0;  // chunk step t
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -551,7 +574,7 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
         __syncthreads();
         for (int t = 0; t < T; ++t) {
             const bool last_of_item = ck_cur + 1 == nchunks;
-            const int it_nxt = last_of_item ? it_cur + G : it_cur;
+            const int it_nxt = last_of_item ? it_cur + its : it_cur;
             const int ck_nxt = last_of_item ? 0 : ck_cur + 1;
             // U of the next chunk step (the last step re-reads its own: no branch in the chain)
             const bool more = t + 1 < T;
@@ -618,11 +641,11 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
         }
     } else {
         if (PC_DBG(32)) __builtin_amdgcn_s_setprio(2);
-        int it_cur = (int)blockIdx.x, ck_cur = 0;  // chunk step s (what the multipliers are on)
+        int it_cur = it0, ck_cur = 0;  // chunk step s (what the multipliers are on)
         int it_ld = it_cur, ck_ld = pair;          // the chunk step whose patch loads were issued last (this wave: s = pair mod 2)
         auto next_load = [&]() __attribute__((always_inline)) {
             ck_ld += 2;
-            if (ck_ld >= nchunks) { ck_ld -= nchunks; it_ld += G; setup_item(it_ld); }
+            if (ck_ld >= nchunks) { ck_ld -= nchunks; it_ld += its; setup_item(it_ld); }
             load_patch(ck_ld);
         };
         setup_item(it_ld);
@@ -642,39 +665,39 @@ __global__ __launch_bounds__(512, 1) void winograd_pc_kernel(const WinoParams p)
             }
             // output transform of the item the multipliers finished one step ago: its two halves in the first two steps of
             // this item (S is next written at the end of this item's last step)
-            if (it_cur != (int)blockIdx.x) {
+            if (it_cur != it0) {
                 if (!fancy) {
                     if (nchunks >= 3) {
-                        if (ck_cur < 2) epilogue_plain(it_cur - G, ck_cur);
+                        if (ck_cur < 2) epilogue_plain(it_cur - its, ck_cur);
                     } else if (ck_cur == 0) {
-                        epilogue_plain(it_cur - G, 0);
-                        epilogue_plain(it_cur - G, 1);
+                        epilogue_plain(it_cur - its, 0);
+                        epilogue_plain(it_cur - its, 1);
                     }
                 } else if (nchunks >= 3) {
                     // (issuing the reads of half e a step before finishing it was measured slower: 119 / 92 / 81 / 83 us against
                     // 113 / 88 / 79 / 86 for the accumulating form)
                     if (ck_cur < 2) {
-                        epi_issue(it_cur - G, ck_cur);
-                        epi_finish(it_cur - G, ck_cur);
+                        epi_issue(it_cur - its, ck_cur);
+                        epi_finish(it_cur - its, ck_cur);
                     }
                 } else if (ck_cur == 0) {
                     for (int eh = 0; eh < 2; ++eh) {
-                        epi_issue(it_cur - G, eh);
-                        epi_finish(it_cur - G, eh);
+                        epi_issue(it_cur - its, eh);
+                        epi_finish(it_cur - its, eh);
                     }
                 }
             }
             if (PC_DBG(64) && blockIdx.x == 0 && wave == 4 && lane == 0 && s < 64) p.tdbg[s * 8 + 2] = __builtin_readcyclecounter();
             __syncthreads();
             if (PC_DBG(64) && blockIdx.x == 0 && wave == 4 && lane == 0 && s < 64) p.tdbg[s * 8 + 3] = __builtin_readcyclecounter();
-            if (++ck_cur == nchunks) { ck_cur = 0; it_cur += G; }
+            if (++ck_cur == nchunks) { ck_cur = 0; it_cur += its; }
         }
         for (int eh = 0; eh < 2; ++eh) {
             if (!fancy) {
-                epilogue_plain(it_cur - G, eh);
+                epilogue_plain(it_cur - its, eh);
             } else {
-                epi_issue(it_cur - G, eh);
-                epi_finish(it_cur - G, eh);
+                epi_issue(it_cur - its, eh);
+                epi_finish(it_cur - its, eh);
             }
         }
     }
@@ -1004,6 +1027,24 @@ static int wino_fwd_launch(const float* x, const float* u, float* y, int N, int 
         // free for whatever else is resident
         const int rounds = (p.items + cus - 1) / cus;
         const int grid = (p.items + rounds - 1) / rounds;
+        // XCD-aware item order (see the kernel): gk channel-block groups x gt = 8 / gk tile-block groups of XCDs; per launch the
+        // L2s then fetch about |U| gt + |x| gk bytes (every XCD of a tile-block group reads that group's x once per channel
+        // group it is in; every U slice is read by the gt XCDs that share it) - pick the minimum.  DS6G_PC_XCD=0 switches
+        // it off, 1 / 2 / 4 / 8 force gk.
+        {
+            static const int xcd_env = [] { const char* e = getenv("DS6G_PC_XCD"); return e ? atoi(e) : -1; }();
+            const int kblocks = K / PC_KB, ntb = p.items / kblocks;
+            p.xcd_gk = 0;
+            if (xcd_env != 0 && grid % 8 == 0 && p.items % grid == 0) {
+                double best = 0;
+                for (int gk = 1; gk <= 8; gk *= 2) {
+                    const int gt = 8 / gk;
+                    if (kblocks % gk || ntb % gt || (xcd_env > 0 && gk != xcd_env)) continue;
+                    const double cost = (double)p.u_bytes * gt + (double)p.x_bytes * gk;
+                    if (!p.xcd_gk || cost < best) { best = cost; p.xcd_gk = gk; }
+                }
+            }
+        }
 #ifdef DS6G_WINO_ABLATE
         static unsigned long long* tdbg = nullptr;
         if ((p.dbg & 64) && !tdbg) { (void)hipMalloc(&tdbg, 64 * 8 * 8); }

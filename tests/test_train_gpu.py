@@ -185,7 +185,6 @@ def test_captured_train_step_is_bit_identical_to_eager(dev, mode):
                 after = (model.flat_parameters()[0], opt.m, opt.v, opt.shadow, *model.buffers())
                 assert all(torch.equal(x, y) for x, y in zip(before, after))
                 assert opt.step_count == 0 and model._salt_host == 0 == int(model._salt.item())
-                assert all(p.grad is None for p in model.parameters())
                 with pytest.raises(ValueError):
                     CapturedTrainStep(model, opt, batches[0], ema, warmup=0)
                 for b in batches[1:]:
