@@ -13,6 +13,31 @@ constexpr int BN_ROWS_PER_THREAD = 16;
 // finalize kernels: 256 threads = 8 columns x 32 partial-groups; each group strides over the row-block partials
 constexpr int FIN_COLS = 8;
 constexpr int FIN_GROUPS = 32;
+// BatchNorm finalize kernels (152 launches per training step, each on the critical path of its trunk stream and
+// latency-bound: one dependent chain of partial reads per thread): 2 columns x 128 partial-groups per block, so C / 2
+// blocks each walk nblk / 128 partials (8 blocks x nblk / 32 before: 8.6 us per launch at C = 64)
+constexpr int BNF_COLS = 2;
+constexpr int BNF_GROUPS = 128;
+
+// sum over the BNF_GROUPS partial-groups of a 256-thread block (thread = g * BNF_COLS + cl): lanes of one wave that share
+// cl are reduced by shuffles, the four wave results meet in LDS; valid in the threads with g == 0
+__device__ __forceinline__ void bnf_reduce2(double& a, double& b, double (*red)[4][BNF_COLS]) {
+#pragma unroll
+    for (int o = BNF_COLS; o < 64; o <<= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < BNF_COLS) {
+        red[0][wave][lane] = a;
+        red[1][wave][lane] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < BNF_COLS) {
+        a = red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x];
+        b = red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
+    }
+}
 
 // partial[blk][0][c] = sum_rows a(r,c), partial[blk][1][c] = sum_rows b(r,c) in fp64.
 // MODE 0: a = x, b = x*x.   MODE 1: a = dyeff, b = dyeff * xhat  (BN backward)
@@ -79,23 +104,17 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __
                                                                 float* __restrict__ mean, float* __restrict__ invstd,
                                                                 float* __restrict__ running_mean,
                                                                 float* __restrict__ running_var) {
-    __shared__ double red[2][FIN_GROUPS][FIN_COLS];
-    const int cl = threadIdx.x & (FIN_COLS - 1), g = threadIdx.x / FIN_COLS;
-    const int c = blockIdx.x * FIN_COLS + cl;
+    __shared__ double red[2][4][BNF_COLS];
+    const int cl = threadIdx.x & (BNF_COLS - 1), g = threadIdx.x / BNF_COLS;
+    const int c = blockIdx.x * BNF_COLS + cl;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int b = g; b < nblk; b += FIN_GROUPS) {
+        for (int b = g; b < nblk; b += BNF_GROUPS) {
             s += partial[(size_t)b * 2 * C + c];
             q += partial[(size_t)b * 2 * C + C + c];
         }
-    red[0][g][cl] = s;
-    red[1][g][cl] = q;
-    __syncthreads();
+    bnf_reduce2(s, q, red);
     if (g != 0 || c >= C) return;
-    for (int gg = 1; gg < FIN_GROUPS; ++gg) {
-        s += red[0][gg][cl];
-        q += red[1][gg][cl];
-    }
     const double mu = s / (double)M;
     double var = q / (double)M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -148,23 +167,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
                                                               const float* __restrict__ invstd,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef, int accumulate) {
-    __shared__ double red[2][FIN_GROUPS][FIN_COLS];
-    const int cl = threadIdx.x & (FIN_COLS - 1), g = threadIdx.x / FIN_COLS;
-    const int c = blockIdx.x * FIN_COLS + cl;
+    __shared__ double red[2][4][BNF_COLS];
+    const int cl = threadIdx.x & (BNF_COLS - 1), g = threadIdx.x / BNF_COLS;
+    const int c = blockIdx.x * BNF_COLS + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int b = g; b < nblk; b += FIN_GROUPS) {
+        for (int b = g; b < nblk; b += BNF_GROUPS) {
             s1 += partial[(size_t)b * 2 * C + c];
             s2 += partial[(size_t)b * 2 * C + C + c];
         }
-    red[0][g][cl] = s1;
-    red[1][g][cl] = s2;
-    __syncthreads();
+    bnf_reduce2(s1, s2, red);
     if (g != 0 || c >= C) return;
-    for (int gg = 1; gg < FIN_GROUPS; ++gg) {
-        s1 += red[0][gg][cl];
-        s2 += red[1][gg][cl];
-    }
     if (accumulate) {
         dgamma[c] += (float)s2;
         dbeta[c] += (float)s1;
@@ -458,7 +471,7 @@ static int bn_stats_run(const TX* x, long M, int C, float eps, float momentum, f
                        (const TX*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, rpb, partial,
                        (const float*)nullptr, (const float*)nullptr, PoolGrad{});
     DS6G_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, BNF_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk,
                        M, C, eps, momentum, mean, invstd, running_mean, running_var);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
@@ -495,7 +508,7 @@ static int bn_bwd_run(const TA* dy, const PoolGrad pg, const TA* y_mask, const T
     hipLaunchKernelGGL((bn_reduce_kernel<1, TX, TA>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, x, dy, y_mask, mean,
                        invstd, M, C, rpb, partial, mg, relu_beta, pg);
     DS6G_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk, M,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, BNF_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk, M,
                        C, gamma, invstd, dgamma, dbeta, coef, accumulate_param_grads);
     DS6G_LAUNCH_CHECK();
     const long total4 = M * C / 4;
