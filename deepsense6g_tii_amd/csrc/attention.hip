@@ -22,6 +22,28 @@
 int g_ds6g_attn_percu = 0;
 int g_ds6g_attn_handover = 1;  // 0: backward recomputes S / dP in every kernel (ds6g_set_debug_flags 0x01000000)
 
+// -DDS6G_ATTN_CLOCKS (tools/attn_clocks.py builds its own library): wave 0 of workgroup 0 of attn_bwd_dkv_kernel sums the
+// clocks it spends in each phase of a tile step into g_attn_clk[phase] (s_memtime, 100 MHz-independent shader clock)
+#ifdef DS6G_ATTN_CLOCKS
+__device__ unsigned long long g_attn_clk[16];
+extern "C" int ds6g_attn_clocks_read(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_attn_clk), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_clk), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define ATTN_CLK_DECL() unsigned long long clk_t_ = 0; const bool clk_on_ = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
+#define ATTN_CLK_START() do { __builtin_amdgcn_sched_barrier(0); clk_t_ = __builtin_readcyclecounter(); } while (0)
+#define ATTN_CLK(ph) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_readcyclecounter(); \
+        if (clk_on_) g_attn_clk[ph] += n_ - clk_t_; clk_t_ = n_; } while (0)
+#else
+#define ATTN_CLK_DECL()
+#define ATTN_CLK_START()
+#define ATTN_CLK(ph)
+#endif
+
 namespace {
 
 struct AttnParams {
@@ -674,12 +696,15 @@ __global__ __launch_bounds__(256, (HD <= 16 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
             delta_s[buf][tid] = qn < T ? p.delta[stat_base + qn] : 0.f;
         }
     };
+    ATTN_CLK_DECL();
     auto step = [&](const float* Qcp, const float* Ocp, const float* Qn, const float* On, int qt, int buf, bool more) {
+        ATTN_CLK_START();
         if (more) {
             tile_dma_any<HD, BF>(q_srd, Qn, (unsigned)head_offq, (qt + 1) * 32, T, p.ldq, wave, lane);
             tile_dma_any<HD, BF>(do_srd, On, (unsigned)head_off, (qt + 1) * 32, T, p.ld, wave, lane);
             stats(qt + 1, buf ^ 1);
         }
+        ATTN_CLK(0);   // DMA issue
         const unsigned Qc = opaque_tile(Qcp), Oc = opaque_tile(Ocp);
         // S[q][key], dP[q][key]: query rows in registers, key on the lane
         f32x16 s, dp;
@@ -687,8 +712,10 @@ __global__ __launch_bounds__(256, (HD <= 16 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
         mma_rows<HD, BF>(s, Qc, kreg, l31, half);
         __builtin_amdgcn_sched_barrier(0);
+        ATTN_CLK(1);   // S product
         if (DO_DK) mma_rows<HD, BF>(dp, Oc, vreg, l31, half);
         __builtin_amdgcn_sched_barrier(0);
+        ATTN_CLK(2);   // dP product
         const int q0 = qt * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -705,6 +732,7 @@ __global__ __launch_bounds__(256, (HD <= 16 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
             }
             s[r] = pr;  // dropped probabilities
         }
+        ATTN_CLK(3);   // elementwise (exp, dropout hash, dS)
         if (HAND) {  // tile image: [reg / 4][lane][reg % 4] - four 1-KiB stores per wave and tensor
             const size_t tile = ((((size_t)(b * p.nh + h) * p.nkg + qt) * p.nkg) + (bx_ * 4 + wave)) * 1024 + lane * 4;
             f32x4* ds_out = reinterpret_cast<f32x4*>(p.hs + tile);
@@ -719,15 +747,23 @@ __global__ __launch_bounds__(256, (HD <= 16 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // phase fences keep the LDS-read prefetch of one product from
+        ATTN_CLK(4);   // hand-over stores issued
         if (DO_DV) mma_dims<HD, BF>(dv, Oc, s, dtab);  // overlapping the live registers of the next
         __builtin_amdgcn_sched_barrier(0);
+        ATTN_CLK(5);   // dV product
         if (DO_DK) mma_dims<HD, BF>(dk, Qc, dp, dtab);
         __builtin_amdgcn_sched_barrier(0);
+        ATTN_CLK(6);   // dK product
         // the next tile's DMA is older than this step's hand-over stores and vmcnt retires in order: wait for the DMA
         // only, the 4 (8) stores drain under the next step
         if (HAND) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PART == 2 ? 8 : 4) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ATTN_CLK(7);   // wait for the next tile's DMA
         __syncthreads();
+        ATTN_CLK(8);   // barrier
+#ifdef DS6G_ATTN_CLOCKS
+        if (clk_on_) g_attn_clk[15] += 1;   // steps counted
+#endif
     };
 
     if (t_begin < t_end) {
