@@ -461,7 +461,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const i32x4 k_srd = make_srd(p.k, p.bytes_q), v_srd = make_srd(p.v, p.bytes_q);
 
     float qreg[HD / 2];
-    load_frag_any<HD, BF>(qreg, p.q, head_offq + (long)(q_row < T ? q_row : T - 1) * p.ldq, half, p.scale);
+    // scores are kept in LOG2 units (q pre-scaled by scale * log2 e): the softmax exponentials are bare v_exp_f32
+    const float scale2 = p.scale * 1.4426950408889634f;
+    load_frag_any<HD, BF>(qreg, p.q, head_offq + (long)(q_row < T ? q_row : T - 1) * p.ldq, half, scale2);
     f32x16 oacc[NB];
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk)
@@ -482,23 +484,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         mma_rows<HD, BF>(s, Kc, qreg, l31, half);
         if (BF == 4) {  // the bf16-stored q fragment is unscaled: scale the scores (exact in fp32)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] *= p.scale;
+            for (int r = 0; r < 16; ++r) s[r] *= scale2;
         }
         const int key0 = kt * 32;
 #ifndef ATTN_ABLATE_SOFTMAX
         float mloc = -INFINITY;
+        if (key0 + 32 > T) {  // only the last key tile has a tail (wave-uniform)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (key0 + krow16(r, half) >= T) s[r] = -INFINITY;
-            mloc = fmaxf(mloc, s[r]);
+            for (int r = 0; r < 16; ++r)
+                if (key0 + krow16(r, half) >= T) s[r] = -INFINITY;
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float mnew = fmaxf(m, mloc);
-        const float alpha = __expf(m - mnew);
+        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
         float lsum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = __expf(s[r] - mnew);
+            s[r] = __builtin_amdgcn_exp2f(s[r] - mnew);
             lsum += s[r];
         }
         l = l * alpha + lsum;
@@ -510,12 +514,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #else
         l += s[0];  // timing experiment only: no softmax arithmetic between the two products
 #endif
-        if (p.thr) {
+        if (p.thr) {  // counters of this lane's 16 keys = one 64-bit base + compile-time offsets (krow16)
+            const Ds6gKeepBase kb(p.seed, seed_off_ + (uint64_t)(drop_row + key0 + 4 * half));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + krow16(r, half);
-                s[r] = ds6g_keep(p.seed, seed_off_ + (uint64_t)(drop_row + key), p.thr) ? s[r] * p.dscale : 0.f;
-            }
+            for (int r = 0; r < 16; ++r) s[r] *= kb.keep((uint32_t)krow16(r, 0), p.thr) ? p.dscale : 0.f;
         }
         mma_dims<HD, BF>(oacc, Vc, s, dtab);
         __builtin_amdgcn_sched_barrier(0);
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     if (p.splits == 1) {
         if (p.out16) store_rows16<HD>(oacc, reinterpret_cast<__bf16*>(p.o) + head_off, p.ld, q_row, T, half, 1.0f / ltot);
         else store_rows<HD>(oacc, p.o + head_off, p.ld, q_row, T, half, 1.0f / ltot);
-        if (half == 0 && q_row < T) p.lse[stat] = m + __logf(ltot);
+        if (half == 0 && q_row < T) p.lse[stat] = (m + __log2f(ltot)) * 0.6931471805599453f;  // natural-log units in HBM
     } else {
         store_rows<HD>(oacc, p.o + (size_t)split * p.slab + head_off, p.ld, q_row, T, half, 1.0f);
         if (half == 0 && q_row < T) {
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(const float* __rest
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < splits; ++s) {
         const float ms = ml[(s * sstride + stat) * 2];
-        const float w = ms == -INFINITY ? 0.f : __expf(ms - m);
+        const float w = ms == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms - m);  // running maxima are in log2 units
         l += ml[(s * sstride + stat) * 2 + 1] * w;
         acc += w * *reinterpret_cast<const f32x4*>(part + (size_t)s * slab + row * ld + c4 * 4);
     }
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(const float* __rest
     } else {
         *reinterpret_cast<f32x4*>(o + row * ld + c4 * 4) = acc;
     }
-    if ((c4 * 4) % hd == 0) lse[stat] = m + __logf(l);
+    if ((c4 * 4) % hd == 0) lse[stat] = (m + __log2f(l)) * 0.6931471805599453f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -629,13 +631,16 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
         mma_rows<HD, BF>(s, Kc, qreg, l31, half);
         mma_rows<HD, BF>(dp, Vc, doreg, l31, half);
         const int key0 = kt * 32;
+        if (p.thr) {
+            const Ds6gKeepBase kb(p.seed, seed_off_ + (uint64_t)(drop_row + key0 + 4 * half));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[r] *= kb.keep((uint32_t)krow16(r, 0), p.thr) ? p.dscale : 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = key0 + krow16(r, half);
             const float pr = (key < T) ? __expf(s[r] - lse) : 0.f;
-            float g = dp[r];
-            if (p.thr) g = ds6g_keep(p.seed, seed_off_ + (uint64_t)(drop_row + key), p.thr) ? g * p.dscale : 0.f;
-            s[r] = pr * (g - delta) * p.scale;  // dS (scaled)
+            s[r] = pr * (dp[r] - delta) * p.scale;  // dS (scaled)
         }
         mma_dims<HD, BF>(dq, Kc, s, dtab);
         __builtin_amdgcn_sched_barrier(0);
@@ -692,7 +697,7 @@ __global__ __launch_bounds__(256, (HD <= 16 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
     auto stats = [&](int qt, int buf) {  // per-query lse / delta of tile qt -> LDS (first 32 threads)
         if (tid < 32) {
             const int qn = qt * 32 + tid;
-            lse_s[buf][tid] = qn < T ? p.lse[stat_base + qn] : INFINITY;
+            lse_s[buf][tid] = qn < T ? p.lse[stat_base + qn] * 1.4426950408889634f : INFINITY;  // log2 units: P = exp2(S scale2 - lse2)
             delta_s[buf][tid] = qn < T ? p.delta[stat_base + qn] : 0.f;
         }
     };
@@ -717,20 +722,28 @@ __global__ __launch_bounds__(256, (HD <= 16 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
         __builtin_amdgcn_sched_barrier(0);
         ATTN_CLK(2);   // dP product
         const int q0 = qt * 32;
+        const float scale2 = p.scale * 1.4426950408889634f;
+        // P = exp(S - lse), dS = P (dP - delta) scale; with attn_drop both carry the keep mask m (0 or 1 / (1 - p)) of their
+        // element: dS = P (m dP - delta) scale, dropped P = m P.  The counters of this lane's 16 queries are one 64-bit base
+        // (query q0 + 4 half, this key) plus krow16 * T: no 64-bit arithmetic and no branch per element.
+        if (p.thr) {
+            const Ds6gKeepBase kb(p.seed, seed_off_ + (uint64_t)((stat_base + q0 + 4 * half) * (long)T + key));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ql = krow16(r, half);
-            float pr = __expf(s[r] * p.scale - lse_s[buf][ql]);  // lse = +inf for q >= T -> 0
-            float g = dp[r];
-            if (p.thr) {
-                const bool keep = ds6g_keep(p.seed, seed_off_ + (uint64_t)((stat_base + q0 + ql) * (long)T + key), p.thr);
-                g = keep ? g * p.dscale : 0.f;
-                dp[r] = pr * (g - delta_s[buf][ql]) * p.scale;
-                pr = keep ? pr * p.dscale : 0.f;
-            } else {
-                dp[r] = pr * (g - delta_s[buf][ql]) * p.scale;
+            for (int r = 0; r < 16; ++r) {
+                const int ql = krow16(r, half);
+                const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], scale2, -lse_s[buf][ql]));  // lse = +inf for q >= T -> 0
+                const float m = kb.keep((uint32_t)(krow16(r, 0) * T), p.thr) ? p.dscale : 0.f;
+                dp[r] = pr * (dp[r] * m - delta_s[buf][ql]) * p.scale;
+                s[r] = pr * m;  // dropped probabilities
             }
-            s[r] = pr;  // dropped probabilities
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = krow16(r, half);
+                const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], scale2, -lse_s[buf][ql]));
+                dp[r] = pr * (dp[r] - delta_s[buf][ql]) * p.scale;
+                s[r] = pr;
+            }
         }
         ATTN_CLK(3);   // elementwise (exp, dropout hash, dS)
         if (HAND) {  // tile image: [reg / 4][lane][reg % 4] - four 1-KiB stores per wave and tensor

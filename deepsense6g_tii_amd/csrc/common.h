@@ -169,6 +169,21 @@ __host__ __device__ __forceinline__ uint32_t ds6g_rand_u32(uint64_t seed, uint64
 __host__ __device__ __forceinline__ bool ds6g_keep(uint64_t seed, uint64_t idx, uint32_t threshold) {
     return ds6g_rand_u32(seed, idx) >= threshold;
 }
+// The same keep(idx) for many counters idx = base + off with small 32-bit offsets (one attention tile: 16 elements per lane
+// and step): the 64-bit add, the multiply of the high counter word and the seed key are paid once per (lane, tile), an
+// element costs the finalizer plus a 32-bit add and a carry select.  Bit-identical to ds6g_keep(seed, base + off, thr)
+// for off < 2^32.
+struct Ds6gKeepBase {
+    uint32_t lo, hic, key;
+    __device__ __forceinline__ Ds6gKeepBase(uint64_t seed, uint64_t base)
+        : lo((uint32_t)base), hic((uint32_t)(base >> 32) * 0x9E3779B9U),
+          key((uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85ebca6bU)) {}
+    __device__ __forceinline__ bool keep(uint32_t off, uint32_t threshold) const {
+        const uint32_t l = lo + off;
+        const uint32_t h = hic + (l < off ? 0x9E3779B9U : 0U);   // carry into the high word: (hi + 1) * C = hi * C + C
+        return ds6g_hash32(l ^ key ^ h) >= threshold;
+    }
+};
 static inline uint32_t ds6g_drop_threshold(float p) {
     if (p <= 0.f) return 0u;
     double t = (double)p * 4294967296.0;
