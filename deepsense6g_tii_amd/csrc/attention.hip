@@ -95,25 +95,6 @@ __device__ __forceinline__ int swz(int r) {
     return (r >> 2) & 3;
 }
 
-// DMA one 32 x HD tile (rows row0.. of the [B*T][ld] tensor behind srd, zero beyond T) into lds_tile
-template <int HD>
-__device__ __forceinline__ void tile_dma(const i32x4 srd, const float* lds_tile, unsigned base_off, int row0, int T,
-                                         int ld, int wave, int lane) {
-    constexpr int NC = HD / 4;
-    constexpr int NWI = HD / 8;  // wave-instructions (64 chunks) per tile
-#pragma unroll
-    for (int j = 0; j < (NWI + 3) / 4; ++j) {
-        const int wi = wave + 4 * j;
-        if (wi < NWI) {
-            const int g = wi * 64 + lane;
-            const int row = g / NC, pos = g % NC;
-            const int c = pos ^ swz<HD>(row);
-            const unsigned off = base_off + (unsigned)(row0 + row) * (unsigned)ld + (unsigned)(c * 4);
-            dma16(srd, lds_addr(lds_tile) + (unsigned)wi * 1024u, (row0 + row) < T ? off * 4u : OOB_OFF);
-        }
-    }
-}
-
 // Tiles are addressed by their LDS BYTE address, laundered once per loop step through an empty asm: the swizzled
 // per-lane addresses are loop-invariant, and hipcc would otherwise hoist ~250 of them out of the tile loop into
 // VGPRs (spilling the dK/dV kernel).  Recomputing them next to each read is free under the 64-cycle MFMAs.
@@ -132,6 +113,39 @@ __device__ __forceinline__ f32x4 row_read(unsigned tile, int r, int c) {
 // "dim on the lane": element d = 32*blk + (lane&31) of row krow16(r, half).  The swizzled address splits into a
 // lane part that takes only 8 distinct values (dtab, built once per kernel) and a compile-time part that folds
 // into the ds_read offset field:   row = cr + 4*half with bit 2 of cr clear, so the row XOR is (const) ^ (half term).
+// Exact-fp32 path at HD >= 64 ("vector dims"): a lane owns NB = HD / 32 CONSECUTIVE head dims (NB * l31 ..) instead of one dim
+// per 32-dim block, so its A operands of all NB blocks of one k-step are ONE ds_read_b128 (HD 128) / ds_read_b64 (HD 64) -
+// 16 LDS reads per product instead of 64 / 32 (measured in attn_bwd_dkv_kernel<128>: the dim-on-the-lane product took 5 750
+// clocks per tile for 4 096 of MFMA, the row-on-the-lane products with their 16 ds_read_b128 4 700).  Accumulator register r
+// of block b then holds dim NB * krow16(r, half) + b (store_rows).  The reads stay conflict-free: the 32 lanes of a half
+// cover one whole swizzled row.
+template <int HD, int BF>
+__device__ __forceinline__ constexpr bool vdims() { return BF == 0 && HD >= 64; }
+template <int HD>
+__device__ __forceinline__ void make_dtab_v(unsigned* dtab, int l31, int half) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        // row XOR (swz<HD>, HD >= 64) = row & 15 = (cr & 15) | 4 half with cr & 15 in {0,1,2,3,8,9,10,11} <-> k = (cr & 3) | bit3 << 2
+        const int xv = (k & 3) | ((k >> 2) << 3);
+        if (HD >= 128) dtab[k] = (unsigned)(4 * half * HD * 4 + (((l31 ^ (4 * half) ^ xv) & 31) << 4));
+        else dtab[k] = (unsigned)(4 * half * HD * 4 + ((((l31 >> 1) ^ (4 * half) ^ xv) & 15) << 4) + (l31 & 1) * 8);
+    }
+}
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const f32x2_ lds_cf2;
+// the lane's NB consecutive dims of row krow16(r, half): v[b] is the A operand of block b
+template <int HD>
+__device__ __forceinline__ void dimv_read(float* v, unsigned tile, const unsigned* dtab, int r) {
+    const int cr = krow16(r, 0);
+    if (HD >= 128) {
+        const f32x4 t = *reinterpret_cast<lds_cf4*>(tile + dtab[(cr & 3) | (((cr >> 3) & 1) << 2)] + (unsigned)(cr * HD * 4));
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    } else {
+        const f32x2_ t = *reinterpret_cast<lds_cf2*>(tile + dtab[(cr & 3) | (((cr >> 3) & 1) << 2)] + (unsigned)(cr * HD * 4));
+        v[0] = t[0]; v[1] = t[1];
+    }
+}
+
 template <int HD>
 __device__ __forceinline__ void make_dtab(unsigned* dtab, int l31, int half) {
     constexpr int NC = HD / 4;
@@ -161,24 +175,6 @@ __device__ __forceinline__ int swz16(int r) {
     if (HD == 64) return (((r >> 1) & 1) << 2) | ((r >> 2) & 3);
     if (HD == 32) return (r >> 2) & 3;
     return (r >> 3) & 1;
-}
-// base_off / ld in ELEMENTS; one wave-instruction = 1 KiB = 512 / HD rows
-template <int HD>
-__device__ __forceinline__ void tile_dma16(const i32x4 srd, const float* lds_tile, unsigned base_off, int row0, int T,
-                                           int ld, int wave, int lane) {
-    constexpr int NC8 = HD / 8;
-    constexpr int NWI = HD / 16;  // wave-instructions per 32-row tile
-#pragma unroll
-    for (int j = 0; j < (NWI + 3) / 4; ++j) {
-        const int wi = wave + 4 * j;
-        if (wi < NWI) {
-            const int g = wi * 64 + lane;
-            const int row = g / NC8, pos = g % NC8;
-            const int c = pos ^ swz16<HD>(row);
-            const unsigned off = base_off + (unsigned)(row0 + row) * (unsigned)ld + (unsigned)(c * 8);
-            dma16(srd, lds_addr(lds_tile) + (unsigned)wi * 1024u, (row0 + row) < T ? off * 2u : OOB_OFF);
-        }
-    }
 }
 typedef __attribute__((address_space(3))) const bf16x8 lds_cb8;
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
@@ -212,9 +208,6 @@ __device__ __forceinline__ void load_frag16(float* reg, const float* base, long 
     }
 }
 template <int HD, int BF>
-__device__ __forceinline__ void tile_dma_any(const i32x4 srd, const float* lds_tile, unsigned base_off, int row0, int T, int ld,
-                                             int wave, int lane);
-template <int HD, int BF>
 __device__ __forceinline__ void load_frag_any(float* reg, const float* base, long row_off, int half, float mul);
 
 // per-lane operand fragment of row `row` for the transposed products: element ss <-> dim half*HD/2 + ss
@@ -227,12 +220,44 @@ __device__ __forceinline__ void load_frag(float* reg, const float* base, long ro
     }
 }
 
+// LDS-DMA of 32 x HD tiles (rows row0 .. row0 + 31 of ONE batch element's [T][ld] block, head h) into the swizzled LDS
+// image: fp32 tiles [row][HD] with the 16-B chunk index XOR swz<HD>(row), bf16 tiles (BF == 4) with swz16<HD>(row); one
+// wave-instruction moves 1 KiB, wave w issues the pieces w, w + 4, ...  Everything that does not change from tile to tile
+// is computed ONCE per kernel: the lane's byte offset of each of its pieces inside a tile at row 0 (division, modulo,
+// swizzle, head column), so a tile costs one add and one DMA instruction per piece (measured before: 1 200 clocks of address
+// arithmetic per tile pair in attn_bwd_dkv_kernel<128>).  The buffer descriptor covers exactly this batch element's T
+// rows, so the tail rows of the last tile (and whole tiles beyond T) fall off its end and the hardware writes zeros for
+// them - no per-lane row test.
 template <int HD, int BF>
-__device__ __forceinline__ void tile_dma_any(const i32x4 srd, const float* lds_tile, unsigned base_off, int row0, int T, int ld,
-                                             int wave, int lane) {
-    if (BF == 4) tile_dma16<HD>(srd, lds_tile, base_off, row0, T, ld, wave, lane);
-    else tile_dma<HD>(srd, lds_tile, base_off, row0, T, ld, wave, lane);
-}
+struct TileLoader {
+    static constexpr int EL = BF == 4 ? 2 : 4;        // bytes per element
+    static constexpr int CH = 16 / EL;                // elements per 16-B chunk
+    static constexpr int NC = HD / CH;                // chunks per row
+    static constexpr int NWI = NC / 2;                // wave-instructions (64 chunks) per 32-row tile
+    static constexpr int NP = (NWI + 3) / 4;          // pieces per wave
+    i32x4 srd;
+    unsigned voff[NP];
+    unsigned row_bytes;
+    __device__ __forceinline__ TileLoader(const float* tensor, long batch_off, int T, int ld, int col0, int wave, int lane) {
+        const char* base = reinterpret_cast<const char*>(tensor) + batch_off * EL;
+        srd = make_srd(base, (unsigned)((long)T * ld * EL));
+        row_bytes = (unsigned)(ld * EL);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int g = (wave + 4 * j) * 64 + lane;
+            const int row = g / NC, pos = g % NC;
+            const int c = pos ^ (BF == 4 ? swz16<HD>(row) : swz<HD>(row));
+            voff[j] = (unsigned)((row * ld + col0 + c * CH) * EL);
+        }
+    }
+    __device__ __forceinline__ void issue(const float* lds_tile, int row0, int wave) const {
+        const unsigned rb = (unsigned)row0 * row_bytes;
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            if (NWI >= 4 || wave + 4 * j < NWI) dma16(srd, lds_addr(lds_tile) + (unsigned)(wave + 4 * j) * 1024u, voff[j] + rb);
+    }
+};
+
 // bf16 storage: the fragment stays packed bf16 and is NOT scaled (callers scale the product instead; mul 0 = zero it)
 template <int HD, int BF>
 __device__ __forceinline__ void load_frag_any(float* reg, const float* base, long row_off, int half, float mul) {
@@ -363,6 +388,24 @@ __device__ __forceinline__ void mma_dims(f32x16* acc, unsigned tile, const f32x1
         }
         return;
     }
+    if constexpr (vdims<HD, BF>()) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a[NB];
+            dimv_read<HD>(a, tile, dtab, r);
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[blk], p[r], acc[blk], 0, 0, 0);
+        }
+        // one wide LDS read per k-step, issued one step ahead of the NB MFMAs that consume it
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int r = 0; r < 14; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, NB, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NB, 0);
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
 #pragma unroll
@@ -381,11 +424,21 @@ __device__ __forceinline__ void mma_dims(f32x16* acc, unsigned tile, const f32x1
 }
 
 // write an accumulator set acc[blk][16] = X^T[d][row] to global X[row][d] (row on the lane)
-template <int HD>
+template <int HD, int BF>
 __device__ __forceinline__ void store_rows16(const f32x16* acc, __bf16* base, int ld, int row, int T, int half, float mul) {
     constexpr int NB = (HD + 31) / 32;
     typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
     if (row >= T) return;
+    if constexpr (vdims<HD, BF>()) {   // register r of block b = dim NB * krow16(r, half) + b
+#pragma unroll
+        for (int r = 0; r < 16; r += (NB == 4 ? 1 : 2)) {
+            const int d = NB * krow16(r, half);
+            const float v0 = acc[0][r] * mul, v1 = acc[1][r] * mul;
+            const float v2 = (NB == 4 ? acc[2][r] : acc[0][r + 1]) * mul, v3 = (NB == 4 ? acc[3][r] : acc[1][r + 1]) * mul;
+            *reinterpret_cast<bf16x4_*>(base + (long)row * ld + d) = bf16x4_{(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+        }
+        return;
+    }
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
 #pragma unroll
@@ -398,10 +451,20 @@ __device__ __forceinline__ void store_rows16(const f32x16* acc, __bf16* base, in
         }
     }
 }
-template <int HD>
+template <int HD, int BF>
 __device__ __forceinline__ void store_rows(const f32x16* acc, float* base, int ld, int row, int T, int half, float mul) {
     constexpr int NB = (HD + 31) / 32;
     if (row >= T) return;
+    if constexpr (vdims<HD, BF>()) {   // register r of block b = dim NB * krow16(r, half) + b
+#pragma unroll
+        for (int r = 0; r < 16; r += (NB == 4 ? 1 : 2)) {
+            const int d = NB * krow16(r, half);
+            const f32x4 v = {acc[0][r] * mul, acc[1][r] * mul, (NB == 4 ? acc[2][r] : acc[0][r + 1]) * mul,
+                             (NB == 4 ? acc[3][r] : acc[1][r + 1]) * mul};
+            *reinterpret_cast<f32x4*>(base + (long)row * ld + d) = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
 #pragma unroll
@@ -450,7 +513,7 @@ __device__ __forceinline__ void store_rows(const f32x16* acc, float* base, int l
     const int t_begin = split * p.tiles_per_split;                                                     \
     const int t_end = min(ntiles, t_begin + p.tiles_per_split);                                        \
     unsigned dtab[8];                                                                                  \
-    make_dtab<HD>(dtab, l31, half);                                                                    \
+    if (vdims<HD, BF>()) make_dtab_v<HD>(dtab, l31, half); else make_dtab<HD>(dtab, l31, half);        \
     (void)NB;
 
 // ------------------------------------------------------------------------------------------------
@@ -458,7 +521,8 @@ template <int HD, int BF>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     ATTN_COMMON();
     const int q_row = bx_ * 128 + wave * 32 + l31;
-    const i32x4 k_srd = make_srd(p.k, p.bytes_q), v_srd = make_srd(p.v, p.bytes_q);
+    const TileLoader<HD, BF> k_ld(p.k, (long)b * T * p.ldq, T, p.ldq, h * HD, wave, lane);
+    const TileLoader<HD, BF> v_ld(p.v, (long)b * T * p.ldq, T, p.ldq, h * HD, wave, lane);
 
     float qreg[HD / 2];
     // scores are kept in LOG2 units (q pre-scaled by scale * log2 e): the softmax exponentials are bare v_exp_f32
@@ -474,8 +538,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 
     auto step = [&](const float* Kcp, const float* Vcp, const float* Kn, const float* Vn, int kt, bool more) {
         if (more) {
-            tile_dma_any<HD, BF>(k_srd, Kn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
-            tile_dma_any<HD, BF>(v_srd, Vn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
+            k_ld.issue(Kn, (kt + 1) * 32, wave);
+            v_ld.issue(Vn, (kt + 1) * 32, wave);
         }
         const unsigned Kc = opaque_tile(Kcp), Vc = opaque_tile(Vcp);
         f32x16 s;
@@ -526,8 +590,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     };
 
     if (t_begin < t_end) {
-        tile_dma_any<HD, BF>(k_srd, Xa0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
-        tile_dma_any<HD, BF>(v_srd, Xb0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
+        k_ld.issue(Xa0, t_begin * 32, wave);
+        v_ld.issue(Xb0, t_begin * 32, wave);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -538,11 +602,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const float ltot = l + __shfl_xor(l, 32, 64);
     const long stat = (long)(b * p.nh + h) * T + q_row;
     if (p.splits == 1) {
-        if (p.out16) store_rows16<HD>(oacc, reinterpret_cast<__bf16*>(p.o) + head_off, p.ld, q_row, T, half, 1.0f / ltot);
-        else store_rows<HD>(oacc, p.o + head_off, p.ld, q_row, T, half, 1.0f / ltot);
+        if (p.out16) store_rows16<HD, BF>(oacc, reinterpret_cast<__bf16*>(p.o) + head_off, p.ld, q_row, T, half, 1.0f / ltot);
+        else store_rows<HD, BF>(oacc, p.o + head_off, p.ld, q_row, T, half, 1.0f / ltot);
         if (half == 0 && q_row < T) p.lse[stat] = (m + __log2f(ltot)) * 0.6931471805599453f;  // natural-log units in HBM
     } else {
-        store_rows<HD>(oacc, p.o + (size_t)split * p.slab + head_off, p.ld, q_row, T, half, 1.0f);
+        store_rows<HD, BF>(oacc, p.o + (size_t)split * p.slab + head_off, p.ld, q_row, T, half, 1.0f);
         if (half == 0 && q_row < T) {
             float* mlp = p.ml + ((size_t)split * p.B * p.nh * T + stat) * 2;
             mlp[0] = m;
@@ -592,7 +656,8 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
     ATTN_COMMON();
     const int q_row = bx_ * 128 + wave * 32 + l31;
     const bool q_ok = q_row < T;
-    const i32x4 k_srd = make_srd(p.k, p.bytes_q), v_srd = make_srd(p.v, p.bytes_q);
+    const TileLoader<HD, BF> k_ld(p.k, (long)b * T * p.ldq, T, p.ldq, h * HD, wave, lane);
+    const TileLoader<HD, BF> v_ld(p.v, (long)b * T * p.ldq, T, p.ldq, h * HD, wave, lane);
 
     float qreg[HD / 2], doreg[HD / 2];
     float delta = 0.f;
@@ -621,8 +686,8 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
 
     auto step = [&](const float* Kcp, const float* Vcp, const float* Kn, const float* Vn, int kt, bool more) {
         if (more) {
-            tile_dma_any<HD, BF>(k_srd, Kn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
-            tile_dma_any<HD, BF>(v_srd, Vn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
+            k_ld.issue(Kn, (kt + 1) * 32, wave);
+            v_ld.issue(Vn, (kt + 1) * 32, wave);
         }
         const unsigned Kc = opaque_tile(Kcp), Vc = opaque_tile(Vcp);
         f32x16 s, dp;
@@ -649,8 +714,8 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
     };
 
     if (t_begin < t_end) {
-        tile_dma_any<HD, BF>(k_srd, Xa0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
-        tile_dma_any<HD, BF>(v_srd, Xb0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
+        k_ld.issue(Xa0, t_begin * 32, wave);
+        v_ld.issue(Xb0, t_begin * 32, wave);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -658,9 +723,9 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
         step(Xa0, Xb0, Xa1, Xb1, kt, kt + 1 < t_end);
         if (kt + 1 < t_end) step(Xa1, Xb1, Xa0, Xb0, kt + 1, kt + 2 < t_end);
     }
-    if (p.splits == 1 && p.out16) store_rows16<HD>(dq, reinterpret_cast<__bf16*>(p.dq) + head_offd, p.ldd, q_row, T, half, 1.0f);
-    else if (p.splits == 1) store_rows<HD>(dq, p.dq + head_offd, p.ldd, q_row, T, half, 1.0f);
-    else store_rows<HD>(dq, p.dq + (size_t)split * p.slab + head_off, p.ld, q_row, T, half, 1.0f);
+    if (p.splits == 1 && p.out16) store_rows16<HD, BF>(dq, reinterpret_cast<__bf16*>(p.dq) + head_offd, p.ldd, q_row, T, half, 1.0f);
+    else if (p.splits == 1) store_rows<HD, BF>(dq, p.dq + head_offd, p.ldd, q_row, T, half, 1.0f);
+    else store_rows<HD, BF>(dq, p.dq + (size_t)split * p.slab + head_off, p.ld, q_row, T, half, 1.0f);
 }
 
 // dK, dV: one wave = 32 keys (key on the lane), loop over (a split of) the query tiles.
@@ -679,7 +744,8 @@ __global__ __launch_bounds__(256, (HD <= 16 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
     __shared__ float delta_s[2][32];
     const int key = bx_ * 128 + wave * 32 + l31;
     const bool key_ok = key < T;
-    const i32x4 q_srd = make_srd(p.q, p.bytes_q), do_srd = make_srd(p.d_o, p.bytes);
+    const TileLoader<HD, BF> q_ld(p.q, (long)b * T * p.ldq, T, p.ldq, h * HD, wave, lane);
+    const TileLoader<HD, BF> do_ld(p.d_o, (long)b * T * p.ld, T, p.ld, h * HD, wave, lane);
 
     float kreg[HD / 2], vreg[HD / 2];
     {
@@ -705,8 +771,8 @@ __global__ __launch_bounds__(256, (HD <= 16 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
     auto step = [&](const float* Qcp, const float* Ocp, const float* Qn, const float* On, int qt, int buf, bool more) {
         ATTN_CLK_START();
         if (more) {
-            tile_dma_any<HD, BF>(q_srd, Qn, (unsigned)head_offq, (qt + 1) * 32, T, p.ldq, wave, lane);
-            tile_dma_any<HD, BF>(do_srd, On, (unsigned)head_off, (qt + 1) * 32, T, p.ld, wave, lane);
+            q_ld.issue(Qn, (qt + 1) * 32, wave);
+            do_ld.issue(On, (qt + 1) * 32, wave);
             stats(qt + 1, buf ^ 1);
         }
         ATTN_CLK(0);   // DMA issue
@@ -780,8 +846,8 @@ __global__ __launch_bounds__(256, (HD <= 16 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
     };
 
     if (t_begin < t_end) {
-        tile_dma_any<HD, BF>(q_srd, Xa0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
-        tile_dma_any<HD, BF>(do_srd, Xb0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
+        q_ld.issue(Xa0, t_begin * 32, wave);
+        do_ld.issue(Xb0, t_begin * 32, wave);
         stats(t_begin, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -791,14 +857,14 @@ __global__ __launch_bounds__(256, (HD <= 16 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
         if (qt + 1 < t_end) step(Xa1, Xb1, Xa0, Xb0, qt + 1, 1, qt + 2 < t_end);
     }
     if (p.splits == 1 && p.out16) {
-        if (DO_DK) store_rows16<HD>(dk, reinterpret_cast<__bf16*>(p.dk) + head_offd, p.ldd, key, T, half, 1.0f);
-        if (DO_DV) store_rows16<HD>(dv, reinterpret_cast<__bf16*>(p.dv) + head_offd, p.ldd, key, T, half, 1.0f);
+        if (DO_DK) store_rows16<HD, BF>(dk, reinterpret_cast<__bf16*>(p.dk) + head_offd, p.ldd, key, T, half, 1.0f);
+        if (DO_DV) store_rows16<HD, BF>(dv, reinterpret_cast<__bf16*>(p.dv) + head_offd, p.ldd, key, T, half, 1.0f);
     } else if (p.splits == 1) {
-        if (DO_DK) store_rows<HD>(dk, p.dk + head_offd, p.ldd, key, T, half, 1.0f);
-        if (DO_DV) store_rows<HD>(dv, p.dv + head_offd, p.ldd, key, T, half, 1.0f);
+        if (DO_DK) store_rows<HD, BF>(dk, p.dk + head_offd, p.ldd, key, T, half, 1.0f);
+        if (DO_DV) store_rows<HD, BF>(dv, p.dv + head_offd, p.ldd, key, T, half, 1.0f);
     } else {
-        if (DO_DK) store_rows<HD>(dk, p.dk + (size_t)split * p.slab + head_off, p.ld, key, T, half, 1.0f);
-        if (DO_DV) store_rows<HD>(dv, p.dv + (size_t)split * p.slab + head_off, p.ld, key, T, half, 1.0f);
+        if (DO_DK) store_rows<HD, BF>(dk, p.dk + (size_t)split * p.slab + head_off, p.ld, key, T, half, 1.0f);
+        if (DO_DV) store_rows<HD, BF>(dv, p.dv + (size_t)split * p.slab + head_off, p.ld, key, T, half, 1.0f);
     }
 }
 
@@ -849,7 +915,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const AttnParams p
     ATTN_GEOM();
     const int q_row = bx_ * 128 + wave * 32 + l31;
     const int qt = bx_ * 4 + wave;
-    const i32x4 k_srd = make_srd(p.k, p.bytes_q);
+    const TileLoader<HD, BF> k_ld(p.k, (long)b * T * p.ldq, T, p.ldq, h * HD, wave, lane);
     f32x16 dq[NB];
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk)
@@ -868,7 +934,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const AttnParams p
     float* tw = Tr[wave];
     auto step = [&](const float* Kcp, const float* Kn, int kt, bool more) {
         if (more) {
-            tile_dma_any<HD, BF>(k_srd, Kn, (unsigned)head_offq, (kt + 1) * 32, T, p.ldq, wave, lane);
+            k_ld.issue(Kn, (kt + 1) * 32, wave);
             fetch(fn, kt + 1);
         }
         const unsigned Kc = opaque_tile(Kcp);
@@ -889,7 +955,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const AttnParams p
         }
     };
     if (t_begin < t_end) {
-        tile_dma_any<HD, BF>(k_srd, Xa0, (unsigned)head_offq, t_begin * 32, T, p.ldq, wave, lane);
+        k_ld.issue(Xa0, t_begin * 32, wave);
         fetch(f, t_begin);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -898,9 +964,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const AttnParams p
         step(Xa0, Xa1, kt, kt + 1 < t_end);
         if (kt + 1 < t_end) step(Xa1, Xa0, kt + 1, kt + 2 < t_end);
     }
-    if (p.splits == 1 && p.out16) store_rows16<HD>(dq, reinterpret_cast<__bf16*>(p.dq) + head_offd, p.ldd, q_row, T, half, 1.0f);
-    else if (p.splits == 1) store_rows<HD>(dq, p.dq + head_offd, p.ldd, q_row, T, half, 1.0f);
-    else store_rows<HD>(dq, p.dq + (size_t)split * p.slab + head_off, p.ld, q_row, T, half, 1.0f);
+    if (p.splits == 1 && p.out16) store_rows16<HD, BF>(dq, reinterpret_cast<__bf16*>(p.dq) + head_offd, p.ldd, q_row, T, half, 1.0f);
+    else if (p.splits == 1) store_rows<HD, BF>(dq, p.dq + head_offd, p.ldd, q_row, T, half, 1.0f);
+    else store_rows<HD, BF>(dq, p.dq + (size_t)split * p.slab + head_off, p.ld, q_row, T, half, 1.0f);
 }
 
 // dV from the dropped-probability tiles of attn_bwd_dkv_kernel<HD, 2, .., HAND = 1> (HD = 128, where the fused dK/dV form
@@ -911,7 +977,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dv2_kernel(const AttnParams p
     __shared__ __attribute__((aligned(16))) float Xb1[32 * HD];
     ATTN_GEOM();
     const int key = bx_ * 128 + wave * 32 + l31;
-    const i32x4 do_srd = make_srd(p.d_o, p.bytes);
+    const TileLoader<HD, BF> do_ld(p.d_o, (long)b * T * p.ld, T, p.ld, h * HD, wave, lane);
     f32x16 dv[NB];
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk)
@@ -929,7 +995,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dv2_kernel(const AttnParams p
     };
     auto step = [&](const float* Ocp, const float* On, int qt, bool more) {
         if (more) {
-            tile_dma_any<HD, BF>(do_srd, On, (unsigned)head_off, (qt + 1) * 32, T, p.ld, wave, lane);
+            do_ld.issue(On, (qt + 1) * 32, wave);
             fetch(sn, qt + 1);
         }
         const unsigned Oc = opaque_tile(Ocp);
@@ -940,7 +1006,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dv2_kernel(const AttnParams p
         if (more) s = sn;
     };
     if (t_begin < t_end) {
-        tile_dma_any<HD, BF>(do_srd, Xb0, (unsigned)head_off, t_begin * 32, T, p.ld, wave, lane);
+        do_ld.issue(Xb0, t_begin * 32, wave);
         fetch(s, t_begin);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -949,9 +1015,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dv2_kernel(const AttnParams p
         step(Xb0, Xb1, qt, qt + 1 < t_end);
         if (qt + 1 < t_end) step(Xb1, Xb0, qt + 1, qt + 2 < t_end);
     }
-    if (p.splits == 1 && p.out16) store_rows16<HD>(dv, reinterpret_cast<__bf16*>(p.dv) + head_offd, p.ldd, key, T, half, 1.0f);
-    else if (p.splits == 1) store_rows<HD>(dv, p.dv + head_offd, p.ldd, key, T, half, 1.0f);
-    else store_rows<HD>(dv, p.dv + (size_t)split * p.slab + head_off, p.ld, key, T, half, 1.0f);
+    if (p.splits == 1 && p.out16) store_rows16<HD, BF>(dv, reinterpret_cast<__bf16*>(p.dv) + head_offd, p.ldd, key, T, half, 1.0f);
+    else if (p.splits == 1) store_rows<HD, BF>(dv, p.dv + head_offd, p.ldd, key, T, half, 1.0f);
+    else store_rows<HD, BF>(dv, p.dv + (size_t)split * p.slab + head_off, p.ld, key, T, half, 1.0f);
 }
 
 // out[row][0..cols) = sum_s part[s][row][0..cols)   (dq / dk / dv split slabs; rows of stride ld_in -> ld_out).
