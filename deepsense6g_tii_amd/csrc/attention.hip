@@ -121,6 +121,14 @@ __device__ __forceinline__ f32x4 row_read(unsigned tile, int r, int c) {
 // cover one whole swizzled row.
 template <int HD, int BF>
 __device__ __forceinline__ constexpr bool vdims() { return BF == 0 && HD >= 64; }
+// Exact-fp32 path at HD = 16: the products whose OUTPUT dimension is the head dim (P V, dS^T Q, P^T dO, dS K) have M = 16.
+// On the 32x32x2 MFMA half of every result row is padding; v_mfma_f32_16x16x1_4b_f32 (four independent 16x16 outer
+// products per instruction, 32 cycles) does the same work without it: lane l belongs to block l / 16, supplies
+// A[dim l % 16] (row krow16(r, half) of the tile) and B[column l % 16] = its own p[r], so the four blocks are
+// (columns 0-15 | 16-31) x (rows of lane-half 0 | 1).  Result register 4 blk + i of lane l = element (dim 4 (l / 16) + i,
+// column l % 16) of block blk: a column's total is block (c / 16) + block (c / 16 + 2), summed when the rows are stored.
+template <int HD, int BF>
+__device__ __forceinline__ constexpr bool quad16() { return BF == 0 && HD == 16; }
 template <int HD>
 __device__ __forceinline__ void make_dtab_v(unsigned* dtab, int l31, int half) {
 #pragma unroll
@@ -149,7 +157,7 @@ __device__ __forceinline__ void dimv_read(float* v, unsigned tile, const unsigne
 template <int HD>
 __device__ __forceinline__ void make_dtab(unsigned* dtab, int l31, int half) {
     constexpr int NC = HD / 4;
-    const int dc = (HD < 32 && l31 >= HD) ? HD - 1 : l31;  // HD = 16: lanes 16..31 re-read a valid element (unused rows)
+    const int dc = HD < 32 ? (l31 & (HD - 1)) : l31;  // HD = 16: lanes 16..31 read dim l31 - 16 (the A operand of their 16x16 block)
     const int hx = NC >= 16 ? 4 * half : (NC == 8 ? 2 * half : half);
 #pragma unroll
     for (int k = 0; k < 8; ++k)
@@ -388,6 +396,19 @@ __device__ __forceinline__ void mma_dims(f32x16* acc, unsigned tile, const f32x1
         }
         return;
     }
+    if constexpr (quad16<HD, BF>()) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(dim_read<HD>(tile, dtab, r, 0), p[r], acc[0], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int r = 0; r < 14; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        return;
+    }
     if constexpr (vdims<HD, BF>()) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -428,6 +449,20 @@ template <int HD, int BF>
 __device__ __forceinline__ void store_rows16(const f32x16* acc, __bf16* base, int ld, int row, int T, int half, float mul) {
     constexpr int NB = (HD + 31) / 32;
     typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+    if constexpr (quad16<HD, BF>()) {  // (see quad16) this lane holds dims 4 (lane / 16) .. + 3 of rows l16 and 16 + l16
+        const int lane = (int)(threadIdx.x & 63), l16 = lane & 15, d = 4 * (lane >> 4);
+        const int r_lo = row - (lane & 31) + l16;
+        const float m_lo = __shfl(mul, l16, 64), m_hi = __shfl(mul, 16 + l16, 64);
+        if (r_lo < T)
+            *reinterpret_cast<bf16x4_*>(base + (long)r_lo * ld + d) =
+                bf16x4_{(__bf16)((acc[0][0] + acc[0][8]) * m_lo), (__bf16)((acc[0][1] + acc[0][9]) * m_lo),
+                        (__bf16)((acc[0][2] + acc[0][10]) * m_lo), (__bf16)((acc[0][3] + acc[0][11]) * m_lo)};
+        if (r_lo + 16 < T)
+            *reinterpret_cast<bf16x4_*>(base + (long)(r_lo + 16) * ld + d) =
+                bf16x4_{(__bf16)((acc[0][4] + acc[0][12]) * m_hi), (__bf16)((acc[0][5] + acc[0][13]) * m_hi),
+                        (__bf16)((acc[0][6] + acc[0][14]) * m_hi), (__bf16)((acc[0][7] + acc[0][15]) * m_hi)};
+        return;
+    }
     if (row >= T) return;
     if constexpr (vdims<HD, BF>()) {   // register r of block b = dim NB * krow16(r, half) + b
 #pragma unroll
@@ -454,6 +489,20 @@ __device__ __forceinline__ void store_rows16(const f32x16* acc, __bf16* base, in
 template <int HD, int BF>
 __device__ __forceinline__ void store_rows(const f32x16* acc, float* base, int ld, int row, int T, int half, float mul) {
     constexpr int NB = (HD + 31) / 32;
+    if constexpr (quad16<HD, BF>()) {  // (see quad16) this lane holds dims 4 (lane / 16) .. + 3 of rows l16 and 16 + l16
+        const int lane = (int)(threadIdx.x & 63), l16 = lane & 15, d = 4 * (lane >> 4);
+        const int r_lo = row - (lane & 31) + l16;
+        const float m_lo = __shfl(mul, l16, 64), m_hi = __shfl(mul, 16 + l16, 64);
+        if (r_lo < T)
+            *reinterpret_cast<f32x4*>(base + (long)r_lo * ld + d) =
+                f32x4{(acc[0][0] + acc[0][8]) * m_lo, (acc[0][1] + acc[0][9]) * m_lo, (acc[0][2] + acc[0][10]) * m_lo,
+                      (acc[0][3] + acc[0][11]) * m_lo};
+        if (r_lo + 16 < T)
+            *reinterpret_cast<f32x4*>(base + (long)(r_lo + 16) * ld + d) =
+                f32x4{(acc[0][4] + acc[0][12]) * m_hi, (acc[0][5] + acc[0][13]) * m_hi, (acc[0][6] + acc[0][14]) * m_hi,
+                      (acc[0][7] + acc[0][15]) * m_hi};
+        return;
+    }
     if (row >= T) return;
     if constexpr (vdims<HD, BF>()) {   // register r of block b = dim NB * krow16(r, half) + b
 #pragma unroll
@@ -571,10 +620,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         }
         l = l * alpha + lsum;
         m = mnew;
+        if constexpr (quad16<HD, BF>()) {  // this lane's accumulators belong to queries l16 and 16 + l16 (see quad16)
+            const float a_lo = __shfl(alpha, lane & 15, 64), a_hi = __shfl(alpha, 16 + (lane & 15), 64);
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk)
+            for (int r = 0; r < 16; ++r) oacc[0][r] *= ((r >> 2) & 1) ? a_hi : a_lo;
+        } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[blk][r] *= alpha;
+            for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[blk][r] *= alpha;
+        }
 #else
         l += s[0];  // timing experiment only: no softmax arithmetic between the two products
 #endif
