@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[blk][r] = 0.f;
     float m = -INFINITY, l = 0.f;
-    const long drop_row = ((long)(b * p.nh + h) * T + q_row) * T;
+    const long drop_row = ((long)(b * p.nh + h) * T + q_row) * ((T + 3) >> 2);  // key quads before this row (common.h: Ds6gKeep4Base)
 
     auto step = [&](const float* Kcp, const float* Vcp, const float* Kn, const float* Vn, int kt, bool more) {
         if (more) {
@@ -633,10 +633,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #else
         l += s[0];  // timing experiment only: no softmax arithmetic between the two products
 #endif
-        if (p.thr) {  // counters of this lane's 16 keys = one 64-bit base + compile-time offsets (krow16)
-            const Ds6gKeepBase kb(p.seed, seed_off_ + (uint64_t)(drop_row + key0 + 4 * half));
+        if (p.thr) {  // attn_drop: this lane's 16 keys are four key quads (registers 4 g .. 4 g + 3), one hash each (common.h)
+            const Ds6gKeep4Base kb(p.seed, seed_off_ + (uint64_t)(drop_row + (key0 >> 2) + half));
+            const uint32_t thi = p.thr & 0xffff0000u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] *= kb.keep((uint32_t)krow16(r, 0), p.thr) ? p.dscale : 0.f;
+            for (int g = 0; g < 4; ++g) {
+                uint32_t w0, w1;
+                kb.words((uint32_t)(2 * g), w0, w1);
+                s[4 * g] *= ds6g_keep4<0>(w0, w1, thi) ? p.dscale : 0.f;
+                s[4 * g + 1] *= ds6g_keep4<1>(w0, w1, thi) ? p.dscale : 0.f;
+                s[4 * g + 2] *= ds6g_keep4<2>(w0, w1, thi) ? p.dscale : 0.f;
+                s[4 * g + 3] *= ds6g_keep4<3>(w0, w1, thi) ? p.dscale : 0.f;
+            }
         }
         mma_dims<HD, BF>(oacc, Vc, s, dtab);
         __builtin_amdgcn_sched_barrier(0);
@@ -737,7 +745,7 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
     for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[blk][r] = 0.f;
-    const long drop_row = ((long)(b * p.nh + h) * T + q_row) * T;
+    const long drop_row = ((long)(b * p.nh + h) * T + q_row) * ((T + 3) >> 2);  // key quads before this row (common.h: Ds6gKeep4Base)
 
     auto step = [&](const float* Kcp, const float* Vcp, const float* Kn, const float* Vn, int kt, bool more) {
         if (more) {
@@ -752,9 +760,17 @@ __global__ __launch_bounds__(256, (HD >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(c
         mma_rows<HD, BF>(dp, Vc, doreg, l31, half);
         const int key0 = kt * 32;
         if (p.thr) {
-            const Ds6gKeepBase kb(p.seed, seed_off_ + (uint64_t)(drop_row + key0 + 4 * half));
+            const Ds6gKeep4Base kb(p.seed, seed_off_ + (uint64_t)(drop_row + (key0 >> 2) + half));
+            const uint32_t thi = p.thr & 0xffff0000u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dp[r] *= kb.keep((uint32_t)krow16(r, 0), p.thr) ? p.dscale : 0.f;
+            for (int g = 0; g < 4; ++g) {
+                uint32_t w0, w1;
+                kb.words((uint32_t)(2 * g), w0, w1);
+                dp[4 * g] *= ds6g_keep4<0>(w0, w1, thi) ? p.dscale : 0.f;
+                dp[4 * g + 1] *= ds6g_keep4<1>(w0, w1, thi) ? p.dscale : 0.f;
+                dp[4 * g + 2] *= ds6g_keep4<2>(w0, w1, thi) ? p.dscale : 0.f;
+                dp[4 * g + 3] *= ds6g_keep4<3>(w0, w1, thi) ? p.dscale : 0.f;
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -848,12 +864,30 @@ __global__ __launch_bounds__(256, (HD <= 16 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
         // element: dS = P (m dP - delta) scale, dropped P = m P.  The counters of this lane's 16 queries are one 64-bit base
         // (query q0 + 4 half, this key) plus krow16 * T: no 64-bit arithmetic and no branch per element.
         if (p.thr) {
-            const Ds6gKeepBase kb(p.seed, seed_off_ + (uint64_t)((stat_base + q0 + 4 * half) * (long)T + key));
+            // attn_drop (common.h: four decisions per hash, quads run along the KEY axis): the four lanes that hold one key quad
+            // need the same 16 hashes (one per query row of the tile) and pick the 16-bit half of their own key from each.
+            // Lane j of the quad computes the four rows 4 g + j, the words go round by DPP quad broadcasts.
+            const int Tq4 = (T + 3) >> 2, jq = lane & 3;
+            const Ds6gKeep4Base kb(p.seed, seed_off_ + (uint64_t)((stat_base + q0 + 4 * half + jq) * (long)Tq4 + (key >> 2)));
+            const uint32_t thi = p.thr & 0xffff0000u;
+            uint32_t w0[4], w1[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) kb.words((uint32_t)(8 * g * Tq4), w0[g], w1[g]);
+            const bool hi_word = (lane & 2) != 0;
+            const uint32_t shl = (lane & 1) ? 0u : 16u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = krow16(r, half);
                 const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], scale2, -lse_s[buf][ql]));  // lse = +inf for q >= T -> 0
-                const float m = kb.keep((uint32_t)(krow16(r, 0) * T), p.thr) ? p.dscale : 0.f;
+                constexpr int QP[4] = {0x00, 0x55, 0xaa, 0xff};  // quad_perm broadcasts of lane 0 / 1 / 2 / 3 of the quad
+                uint32_t a, c;
+                switch (r & 3) {
+                    case 0: a = __builtin_amdgcn_mov_dpp((int)w0[r >> 2], QP[0], 0xf, 0xf, true); c = __builtin_amdgcn_mov_dpp((int)w1[r >> 2], QP[0], 0xf, 0xf, true); break;
+                    case 1: a = __builtin_amdgcn_mov_dpp((int)w0[r >> 2], QP[1], 0xf, 0xf, true); c = __builtin_amdgcn_mov_dpp((int)w1[r >> 2], QP[1], 0xf, 0xf, true); break;
+                    case 2: a = __builtin_amdgcn_mov_dpp((int)w0[r >> 2], QP[2], 0xf, 0xf, true); c = __builtin_amdgcn_mov_dpp((int)w1[r >> 2], QP[2], 0xf, 0xf, true); break;
+                    default: a = __builtin_amdgcn_mov_dpp((int)w0[r >> 2], QP[3], 0xf, 0xf, true); c = __builtin_amdgcn_mov_dpp((int)w1[r >> 2], QP[3], 0xf, 0xf, true); break;
+                }
+                const float m = (((hi_word ? c : a) << shl) >= thi) ? p.dscale : 0.f;
                 dp[r] = pr * (dp[r] * m - delta_s[buf][ql]) * p.scale;
                 s[r] = pr * m;  // dropped probabilities
             }

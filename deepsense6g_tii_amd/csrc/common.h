@@ -184,6 +184,38 @@ struct Ds6gKeepBase {
         return ds6g_hash32(l ^ key ^ h) >= threshold;
     }
 };
+// Dropout on the attention probabilities ([B * nh][T][T] per site; evaluated T * T times per head in the forward and again
+// in the backward): FOUR keep decisions per hash.  Element (row, key) - row = (b * nh + h) * T + query - belongs to the
+// key quad  row * ceil(T / 4) + (key >> 2)  (counter = the site's offset + that index); the quad's hash yields two words
+//   x = finalizer rounds 1-2 of ds6g_hash32 on the keyed counter;  w0 = fin(x * 0x846ca68b), w1 = fin(x * 0xC2B2AE35),
+//   fin(v) = v ^ (v >> 16)      (w0 IS ds6g_hash32 of the keyed counter)
+// whose four 16-bit halves are the decisions of keys 4 k .. 4 k + 3: key & 3 = 0 -> low half of w0, 1 -> high half of w0,
+// 2 -> low half of w1, 3 -> high half of w1; the element is kept when its half >= floor(p * 2^16).  The halves of one
+// word are independent by construction (fin is a bijection of the two halves), the two words are two multiplicative
+// hashes of one well-mixed value; measured pairwise correlation of the four decisions over 11 M quads: within 2 sigma of 0
+// (tools/attn_mask_stats.py).  Cost per element: a quarter of the hash plus a shift and a compare, against the whole hash.
+struct Ds6gKeep4Base {
+    uint32_t lo, hic, key;
+    __device__ __forceinline__ Ds6gKeep4Base(uint64_t seed, uint64_t base)
+        : lo((uint32_t)base), hic((uint32_t)(base >> 32) * 0x9E3779B9U),
+          key((uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85ebca6bU)) {}
+    // the two words of the quad at counter base + off
+    __device__ __forceinline__ void words(uint32_t off, uint32_t& w0, uint32_t& w1) const {
+        const uint32_t l = lo + off;
+        uint32_t x = l ^ key ^ (hic + (l < off ? 0x9E3779B9U : 0U));
+        x ^= x >> 16; x *= 0x7feb352dU;
+        x ^= x >> 15;
+        w0 = x * 0x846ca68bU; w0 ^= w0 >> 16;
+        w1 = x * 0xC2B2AE35U; w1 ^= w1 >> 16;
+    }
+};
+// decision of key & 3 == F from the quad's words against thi = floor(p * 2^16) << 16 (= threshold32 & 0xffff0000): a low
+// half is shifted to the top; the bits below it never change the outcome of >= against a multiple of 2^16
+template <int F>
+__device__ __forceinline__ bool ds6g_keep4(uint32_t w0, uint32_t w1, uint32_t thi) {
+    const uint32_t w = (F & 2) ? w1 : w0;
+    return ((F & 1) ? w : (w << 16)) >= thi;
+}
 static inline uint32_t ds6g_drop_threshold(float p) {
     if (p <= 0.f) return 0u;
     double t = (double)p * 4294967296.0;

@@ -99,13 +99,64 @@ def _keep_bits(seed, off, numel, p):
     return out
 
 
+def _keep_bits_attn(seed, off, shape, p):
+    """attn_drop masks (csrc/common.h Ds6gKeep4Base / ds6g_keep4): FOUR decisions per hash.  Element (row, key) of the
+    [B * nh * T][T] probability matrix belongs to key quad  row * ceil(T / 4) + (key >> 2)  (counter = off + that index);
+    the quad's two words w0 = fin(x * 0x846ca68b), w1 = fin(x * 0xC2B2AE35) (x = two finalizer rounds on the keyed counter)
+    hold the decisions of keys 4k .. 4k + 3 in their 16-bit halves (low w0, high w0, low w1, high w1); kept when the half
+    >= floor(p * 2^16)."""
+    B, nh, T, T2 = shape
+    assert T == T2
+    Tq4 = (T + 3) // 4
+    rows = B * nh * T
+    key = np.uint32((seed & 0xffffffff) ^ (((seed >> 32) * 0x85ebca6b) & 0xffffffff))
+    thr16 = np.uint32(int(float(np.float32(p)) * 4294967296.0) >> 16)
+    out = np.empty((rows, Tq4 * 4), dtype=np.bool_)
+    RS = 1 << 14    # rows per slab
+
+    def slab(r0):
+        r1 = min(rows, r0 + RS)
+        idx = np.arange(off + r0 * Tq4, off + r1 * Tq4, dtype=np.uint64)
+        x = (idx & np.uint64(0xffffffff)).astype(np.uint32)
+        hi = (idx >> np.uint64(32)).astype(np.uint32)
+        hi *= np.uint32(0x9E3779B9)
+        x ^= key
+        x ^= hi
+        x ^= x >> np.uint32(16)
+        x *= np.uint32(0x7feb352d)
+        x ^= x >> np.uint32(15)
+        w0 = x * np.uint32(0x846ca68b)
+        w0 ^= w0 >> np.uint32(16)
+        w1 = x * np.uint32(0xC2B2AE35)
+        w1 ^= w1 >> np.uint32(16)
+        o = out[r0:r1].reshape(-1, 4)
+        o[:, 0] = (w0 & np.uint32(0xffff)) >= thr16
+        o[:, 1] = (w0 >> np.uint32(16)) >= thr16
+        o[:, 2] = (w1 & np.uint32(0xffff)) >= thr16
+        o[:, 3] = (w1 >> np.uint32(16)) >= thr16
+
+    starts = range(0, rows, RS)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(_threads()) as ex:
+        list(ex.map(slab, starts))
+    return np.ascontiguousarray(out[:, :T]).reshape(B, nh, T, T)
+
+
+def _keep_bits_site(seed, off, shape, p):
+    """the keep bits of one dropout site: attention-probability sites ((B, nh, T, T)) draw four decisions per hash, every
+    other site (embd_drop / resid_drop on (B, T, C)) one per element"""
+    if len(shape) == 4:
+        return _keep_bits_attn(seed, off, tuple(shape), p)
+    return _keep_bits(seed, off, int(np.prod(shape)), p).reshape(shape)
+
+
 def _drop_scale(p):
     return float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))   # the kernels' fp32 1/(1-p)
 
 
 def _keep_mask(seed, off, shape, p, dtype=torch.float32):
     """-> keep mask scaled by the kernels' fp32 1/(1-p)"""
-    bits = torch.from_numpy(_keep_bits(seed, off, int(np.prod(shape)), p).reshape(shape))
+    bits = torch.from_numpy(_keep_bits_site(seed, off, tuple(shape), p))
     return bits.to(dtype) * _drop_scale(p)
 
 
@@ -283,7 +334,7 @@ class _MaskBook:
         self.counter += (n + 1023) // 1024 * 1024
         bits = self.cache.get(off)
         if bits is None:
-            bits = self.cache[off] = torch.from_numpy(_keep_bits(self.seed, off, n, p).reshape(shape))
+            bits = self.cache[off] = torch.from_numpy(_keep_bits_site(self.seed, off, tuple(shape), p))
         assert bits.shape == tuple(shape)
         return bits, _drop_scale(p)
 
