@@ -54,7 +54,13 @@ int ds6g_set_debug_flags(int flags);
 int ds6g_set_compute_mode(int mode);
 int ds6g_get_compute_mode(void);
 
-/* Dropout masks are a pure function of (seed, seed_off + element index).  seed_off is a launch argument, frozen when a
+/* Dropout masks are a pure function of (seed, counter).  Elementwise sites (embd_drop, resid_drop: ds6g_dropout, the
+ * linear epilogues, ds6g_layernorm_bwd's dx_drop, the token-pool kernels) use counter = seed_off + element index, one
+ * hash (lowbias32 finalizer on the keyed counter) per element, dropped when hash < floor(p * 2^32).  The attention kernels
+ * (attn_drop on the [B * nh][T][T] probabilities) draw FOUR decisions per hash: element (row, key), row = (b * nh + h) * T +
+ * query, uses counter = seed_off + row * ceil(T / 4) + (key >> 2) and the 16-bit half (key & 3) of the two words derived
+ * from that counter, dropped when the half < floor(p * 2^16) (csrc/common.h Ds6gKeep4Base; numpy restatement in
+ * tests/test_bench_shapes_gpu.py::_keep_bits_attn).  seed_off is a launch argument, frozen when a
  * training step is captured into a hipGraph; ds6g_set_dropout_salt(dev_ptr) makes every kernel that draws a mask add the
  * uint64 at dev_ptr to seed_off when it RUNS (the caller advances that value on the device once per step), so replays draw
  * fresh masks.  Applies to the launches of the calling thread from now on (thread-local); NULL switches it off. */
