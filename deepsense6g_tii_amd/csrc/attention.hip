@@ -21,6 +21,7 @@
 
 int g_ds6g_attn_percu = 0;
 int g_ds6g_attn_handover = 1;  // 0: backward recomputes S / dP in every kernel (ds6g_set_debug_flags 0x01000000)
+int g_ds6g_attn_fused128 = 1;  // 0 (ds6g_set_debug_flags 0x04000000): hd = 128 backward as dK kernel + dropped-P tiles + dV kernel
 
 // -DDS6G_ATTN_CLOCKS (tools/attn_clocks.py builds its own library): wave 0 of workgroup 0 of attn_bwd_dkv_kernel sums the
 // clocks it spends in each phase of a tile step into g_attn_clk[phase] (s_memtime, 100 MHz-independent shader clock)
@@ -1169,6 +1170,7 @@ int launch_hd_bf(const AttnParams& p, int hd, dim3 grid, hipStream_t st) {
         }                                                                                                     \
         if (KIND == 4) hipLaunchKernelGGL((attn_bwd_dv2_kernel<(HDV >= 128 ? HDV : 128), BF>), grid, dim3(256), 0, st, p); \
         if (KIND == 5) hipLaunchKernelGGL((attn_bwd_dq2_kernel<HDV, BF>), grid, dim3(256), 0, st, p);         \
+        if (KIND == 6) hipLaunchKernelGGL((attn_bwd_dkv_kernel<(BF == 0 ? HDV : 16), 0, (BF == 0 ? 0 : BF), 1>), grid, dim3(256), 0, st, p); \
         break;
     switch (hd) {
         ATTN_CASE(16)
@@ -1344,11 +1346,16 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, in
             p.tiles_per_split = cdiv(ntiles, splits);
             p.splits = cdiv(ntiles, p.tiles_per_split);
         };
-        const bool two_pass = hd >= 128;
+        // hd = 128, exact fp32: dK and dV in ONE kernel (one wave per SIMD, 512 registers, 37 of them spilled) instead of the
+        // dK kernel + dropped-P tiles through HBM (201 MB per layer) + attn_bwd_dv2_kernel: measured 690 -> 669 us per
+        // backward at B = 12 (ds6g_set_debug_flags 0x04000000 restores the two-kernel form; the bf16 modes keep it)
+        const bool fused128 = hd >= 128 && g_ds6g_attn_fused128 && !g_ds6g_bf16 && !in16;
+        const bool two_pass = hd >= 128 && !fused128;
         plan(hd >= 128 ? 1 : (hd >= 64 ? 2 : 3), two_pass ? 1 : 2);
         p.dk = p.splits == 1 ? dk : wsf;
         p.dv = p.splits == 1 ? dv : wsf + (size_t)p.splits * slab;
-        int rc = launch_hd<3>(p, hd, dim3(blocks128, nh * p.splits, B), st);
+        int rc = fused128 ? launch_hd<6>(p, hd, dim3(blocks128, nh * p.splits, B), st)
+                          : launch_hd<3>(p, hd, dim3(blocks128, nh * p.splits, B), st);
         if (rc) return rc;
         if (p.splits > 1) {
             hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n4, 256), two_pass ? 1 : 2), dim3(256), 0, st, (const float*)wsf, dk,

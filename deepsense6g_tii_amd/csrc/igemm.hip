@@ -23,6 +23,7 @@
 #include <vector>
 #include <cstdlib>
 
+extern int g_ds6g_attn_fused128;  // attention.hip: hd = 128 backward with the fused dK + dV kernel (experiment)
 extern int g_ds6g_attn_percu;  // attention.hip: split-heuristic override (timing experiments)
 extern int g_ds6g_attn_handover;
 extern int g_wino_kb64;         // winograd.hip: 64-channel workgroups (timing experiments)
@@ -972,6 +973,7 @@ extern "C" {
 int ds6g_set_debug_flags(int flags) {
     g_dbg = flags & 0xbf;  // 0x80: force the general (FAST 0) walk
     g_ds6g_attn_handover = (flags & 0x01000000) ? 0 : 1;
+    g_ds6g_attn_fused128 = (flags & 0x04000000) ? 0 : 1;
     g_ds6g_attn_percu = (flags >> 20) & 0xf;  // attention: resident-workgroups-per-CU assumption of the split heuristic
     g_wino_kb64 = (flags & 0x02000000) ? 1 : 0;
     g_bf16_bk32 = (flags & 0x10000000) ? 0 : 1;

@@ -284,7 +284,14 @@ def test_attention_at_bench_batch(dev, hd, pdrop):
         reco = ops.attention_bwd(qg, kg, vg, og, dog, lse, B, T, nh, ws, **kw)
     finally:
         lib().set_debug_flags(0)
-    for got in (hand, reco):
+    forms = [hand, reco]
+    if hd >= 128:                          # hd 128: the default fuses dK + dV; also the dK kernel + dropped-P tiles + dV kernel form
+        lib().set_debug_flags(0x04000000)
+        try:
+            forms.append(ops.attention_bwd(qg, kg, vg, og, dog, lse, B, T, nh, ws, **kw))
+        finally:
+            lib().set_debug_flags(0)
+    for got in forms:
         close(got[0], q.grad, 1e-4, 2e-5)
         close(got[1], k.grad, 1e-4, 2e-5)
         close(got[2], v.grad, 1e-4, 2e-5)
