@@ -293,6 +293,10 @@ def main():
                     help="1 (single process): the timed steps replay ONE captured HIP graph of the whole iteration "
                          "(train.CapturedTrainStep, bit-identical to the eager iteration); 0: eager launches.  Data-parallel "
                          "runs (--gpus > 1) are always eager (bucketed all-reduce issued from the backward walk)")
+    ap.add_argument("--overlap-optimizer", type=int, default=1,
+                    help="1: the AdamW (+EMA) update of every gradient bucket runs on a side stream as soon as the bucket is "
+                         "final (under data parallelism: all-reduced), overlapping the rest of the backward walk "
+                         "(FusedAdamW.enable_overlap; bit-identical to the plain order); 0: one update after backward")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the three trunks on one stream (per-kernel profiling: durations are not overlapped)")
     ap.add_argument("--debug-flags", type=lambda v: int(v, 0), default=0, help="ds6g_set_debug_flags (tuning experiments)")
@@ -332,6 +336,8 @@ def main():
     if world > 1:
         ddist.broadcast_parameters(model)
         reducer = ddist.attach(model, opt)
+    if args.overlap_optimizer and not args.graph:
+        opt.enable_overlap(model)
     fronts, lidars, radars, gps, target, _ = make_batch(args.batch, cfg.seq_len, cfg.n_views, cfg.add_velocity,
                                                         seed=100 + rank, device=dev)
     if args.image_only:
@@ -477,7 +483,9 @@ def main():
                                    "AdamW, train-mode BN, dropout 0.1",
                        "global_batch": args.batch * world, "seq_len": cfg.seq_len,
                        "parallelism": f"dp{world}", "ema": bool(args.ema),
-                       "launch": "one HIP graph per step" if use_graph else "eager"},
+                       "launch": "one HIP graph per step" if use_graph else "eager",
+                       "optimizer": "AdamW per gradient bucket on a side stream during backward" if (args.overlap_optimizer and not args.graph)
+                                    else "AdamW after backward"},
             "loss": final_loss,
             "algorithmic_gflop_per_sample": 559.3,
             "model_tflops": value * 559.3e9 / 1e12,

@@ -71,6 +71,11 @@ class GradReducer:
         self.force_collective = False
         self.probe_stream = None
         self.probes = []
+        # subscribers (train.FusedAdamW.enable_overlap): on_begin() at the start of every backward walk, on_bucket(lo, hi,
+        # work) right after a bucket was issued - `work` is its all-reduce (None at world size 1): the optimizer updates
+        # the bucket's parameters on its own stream as soon as that has completed, while the backward walk goes on
+        self.on_begin = None
+        self.on_bucket = None
 
     @property
     def world(self):
@@ -79,6 +84,8 @@ class GradReducer:
     def begin(self):
         self.works, self.issued, self.probes = [], [], []
         self.lo = self.hi = 0
+        if self.on_begin is not None:
+            self.on_begin()
 
     def ready(self, k, lo, hi):
         assert lo == self.hi, "gradient milestones must arrive as a contiguous, growing prefix"
@@ -94,10 +101,13 @@ class GradReducer:
                 self.probe_stream.wait_event(ev)
                 with torch.cuda.stream(self.probe_stream):
                     self.probes.append(self.g[self.lo:self.hi].clone())
+            work = None
             if self.world > 1 or (self.force_collective and dist.is_initialized()):
-                self.works.append(dist.all_reduce(self.g[self.lo:self.hi], op=dist.ReduceOp.SUM, group=self.group,
-                                                  async_op=True))
+                work = dist.all_reduce(self.g[self.lo:self.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.works.append(work)
             self.issued.append((self.lo, self.hi))
+            if self.on_bucket is not None:
+                self.on_bucket(self.lo, self.hi, work)
             self.lo = self.hi
 
     def finish(self):

@@ -88,6 +88,67 @@ class FusedAdamW:
         self.ema_decay = ema_decay
         self.shadow = p.clone() if ema_decay is not None else None
         self.grad_scale = 1.0  # 1/world_size under data parallelism (sum all-reduce, scale here)
+        self._overlap = None   # (reducer, side stream) when enable_overlap() is active
+        self._began = False    # this step's optimizer scalars were already advanced by the overlapped path
+        self._applied = 0      # arena prefix already updated by the overlapped buckets of the backward walk in flight
+
+    # ---- the update overlapped with the backward walk -------------------------------------------------------------------
+    def enable_overlap(self, model=None, min_bucket_elems=8 << 20):
+        """AdamW (+EMA) is one HBM-bound pass over 2.2 GB (0.4 ms at bs 12) that the reference runs after backward
+        (train2_seq.py:128-134).  The gradient arena is laid out in backward-completion order, so the parameters of a bucket
+        can be updated the moment the bucket's gradients are final - on a side stream, under the matrix-core-bound rest of
+        the backward walk (under data parallelism: the moment the bucket's all-reduce has completed).  step() then only joins
+        that stream and updates whatever was not covered.  Same arithmetic, same result bit for bit
+        (tests/test_train_gpu.py); a parameter is never updated while a backward kernel may still read it: a bucket is
+        final only after every kernel of its layers was enqueued and the producing streams were joined.  Not available with
+        max_grad_norm (the clip coefficient needs the norm of the whole gradient first).  Call after dist.attach() when
+        both are used."""
+        from . import dist as ddist
+        model = model or self.model
+        if self.max_grad_norm is not None:
+            raise RuntimeError("enable_overlap(): a global-norm clip needs the whole gradient before the first update")
+        red = getattr(model.grad_ready_hook, "__self__", None) if model.grad_ready_hook is not None else None
+        if red is None:   # single process: the reducer is only the bucketing engine (no collective at world size 1)
+            red = ddist.GradReducer(model.flat_parameters()[1], None, min_bucket_elems, flush_at=7)
+            model.grad_ready_hook = red.ready
+        red.on_begin, red.on_bucket = self._overlap_begin, self._overlap_bucket
+        self._overlap = (red, torch.cuda.Stream(model.device))
+        return red
+
+    def _overlap_begin(self):
+        # start of a backward walk: this step's scalars (step count, bias corrections, lr) before its first bucket.  The
+        # reducer's begin() may run more than once per iteration (train_iteration and the model's backward both call it):
+        # the state advances once per step()
+        self._applied = 0
+        if not self._began:
+            self._began = True
+            self._advance_state()
+
+    def _overlap_bucket(self, lo, hi, work):
+        _, side = self._overlap
+        side.wait_stream(torch.cuda.current_stream())   # the bucket is final on the calling stream (producers joined)
+        with torch.cuda.stream(side):
+            if work is not None:
+                work.wait()                             # ... and summed over the ranks
+            self._update_range(lo, hi)
+        assert lo == self._applied
+        self._applied = hi
+
+    def _advance_state(self):
+        self.step_count += 1
+        grp = self.param_groups[0]
+        self.sync_lr()
+        lib().adamw_state_advance(self._dev.data_ptr(), grp["betas"][0], grp["betas"][1], ops._stream())
+
+    def _update_range(self, lo, hi, coef=0):
+        p, g = self.model.flat_parameters()
+        grp = self.param_groups[0]
+        n = hi - lo
+        lib().adamw_step_dev(p.data_ptr() + 4 * lo, g.data_ptr() + 4 * lo, self.m.data_ptr() + 4 * lo, self.v.data_ptr() + 4 * lo,
+                             0 if self.shadow is None else self.shadow.data_ptr() + 4 * lo, n, self._dev.data_ptr(),
+                             grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"],
+                             0.0 if self.ema_decay is None else float(self.ema_decay), float(self.grad_scale), coef,
+                             ops._stream())
 
     def zero_grad(self, set_to_none=True):
         if set_to_none:
@@ -100,20 +161,21 @@ class FusedAdamW:
         if not self.model.params_in_arena():
             raise RuntimeError("parameters were re-pointed away from the arena (EMA shadow applied?): restore first")
         p, g = self.model.flat_parameters()
-        self.step_count += 1
-        grp = self.param_groups[0]
-        self.sync_lr()
-        lib().adamw_state_advance(self._dev.data_ptr(), grp["betas"][0], grp["betas"][1], ops._stream())
+        if self._overlap is not None and self._began:
+            # the backward walk already advanced the step's scalars and updated the prefix [0, _applied) bucket by bucket on
+            # the side stream: join it and finish what is left (nothing when every bucket went through the hook)
+            torch.cuda.current_stream().wait_stream(self._overlap[1])
+            if self._applied < p.numel():
+                self._update_range(self._applied, p.numel())
+            self._applied, self._began = 0, False
+            return
+        self._advance_state()
         coef = 0
         if self.max_grad_norm is not None:
             lib().grad_norm_clip(g.data_ptr(), g.numel(), float(self.max_grad_norm), float(self.grad_scale),
                                  self._clip_out.data_ptr(), self._clip_ws.data_ptr(), self._clip_ws.numel(), ops._stream())
             coef = self._clip_out.data_ptr() + 4
-        lib().adamw_step_dev(p.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                             0 if self.shadow is None else self.shadow.data_ptr(), p.numel(), self._dev.data_ptr(),
-                             grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"],
-                             0.0 if self.ema_decay is None else float(self.ema_decay), float(self.grad_scale), coef,
-                             ops._stream())
+        self._update_range(0, p.numel(), coef)
 
     def sync_lr(self):
         """write the scheduled lr to device memory when it changed (a tiny copy, outside any captured graph)"""

@@ -210,3 +210,47 @@ def test_captured_train_step_is_bit_identical_to_eager(dev, mode):
             assert torch.equal(x, y)
     finally:
         ops.set_compute_mode("f32")
+
+
+def test_optimizer_update_overlapped_with_backward_is_bit_identical(dev):
+    """FusedAdamW.enable_overlap(): the AdamW (+EMA) update of every gradient bucket runs on a side stream the moment the
+    bucket is final, under the rest of the backward walk.  Three iterations (dropout 0.1, trunk streams and the
+    weight-gradient companion stream on, a changed lr in between) must leave parameters, both moments, the EMA shadow, the
+    BatchNorm buffers and the losses bit-identical to the plain zero_grad -> forward -> backward -> step order of
+    Engine.train (train2_seq.py:106-134), and every bucket must have been applied by the hook (step() only joins)."""
+    from deepsense6g_tii_amd.model import GlobalConfig, TransFuser
+    from deepsense6g_tii_amd.train import EMA, FusedAdamW, train_iteration
+    from oracle import fusion_ref as fr
+    kw = dict(n_layer=2)
+    rcfg = fr.RefConfig(**kw)
+    sd = fr.make_state(rcfg, seed=9)
+    batches = [fr.make_inputs(rcfg, 2, seed=70 + i)[:5] for i in range(3)]
+    runs = []
+    for overlap in (False, True):
+        model = TransFuser(GlobalConfig(**kw), dev)
+        model.load_state_dict(sd)
+        model.train()
+        opt = FusedAdamW(model, lr=1e-3, ema_decay=0.999)
+        ema = EMA(model, 0.999, opt)
+        ema.register()
+        red = opt.enable_overlap(model, min_bucket_elems=1 << 20) if overlap else None
+        losses = []
+        for b in batches:
+            opt.param_groups[0]["lr"] *= 0.7
+            loss, _ = train_iteration(model, opt, b, ema)
+            losses.append(float(loss))
+            if overlap:
+                assert len(red.issued) >= 3 and red.issued[-1][1] == model._arena_used and opt._applied == 0
+        torch.cuda.synchronize()
+        runs.append(dict(p=model.flat_parameters()[0].clone(), m=opt.m.clone(), v=opt.v.clone(), sh=opt.shadow.clone(),
+                         bufs=[b.clone() for b in model.buffers()], losses=losses, steps=opt.step_count))
+    a, b = runs
+    assert a["losses"] == b["losses"] and a["steps"] == b["steps"] == 3
+    for k in ("p", "m", "v", "sh"):
+        assert torch.equal(a[k], b[k]), k
+    for x, y in zip(a["bufs"], b["bufs"]):
+        assert torch.equal(x, y)
+    # a global-norm clip needs the whole gradient first: refused, not silently wrong
+    model = TransFuser(GlobalConfig(**kw), dev)
+    with pytest.raises(RuntimeError):
+        FusedAdamW(model, lr=1e-3, max_grad_norm=3.0).enable_overlap(model)
