@@ -10,9 +10,6 @@
 namespace {
 
 constexpr int BN_ROWS_PER_THREAD = 16;
-// finalize kernels: 256 threads = 8 columns x 32 partial-groups; each group strides over the row-block partials
-constexpr int FIN_COLS = 8;
-constexpr int FIN_GROUPS = 32;
 // BatchNorm finalize kernels (152 launches per training step, each on the critical path of its trunk stream and
 // latency-bound: one dependent chain of partial reads per thread): 2 columns x 128 partial-groups per block, so C / 2
 // blocks each walk nblk / 128 partials (8 blocks x nblk / 32 before: 8.6 us per launch at C = 64)
@@ -396,16 +393,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 __global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restrict__ partial, int nblk, int ncol,
                                                            float* __restrict__ out0, float* __restrict__ out1,
                                                            int split_at, int accumulate) {
-    __shared__ double red[FIN_GROUPS][FIN_COLS];
-    const int cl = threadIdx.x & (FIN_COLS - 1), g = threadIdx.x / FIN_COLS;
-    const int c = blockIdx.x * FIN_COLS + cl;
+    // 4 columns x 64 partial-groups per block (like the BatchNorm finalize kernels: latency-bound launches, 68 per step)
+    constexpr int CF_COLS = 4, CF_GROUPS = 64;
+    __shared__ double red[4][CF_COLS];
+    const int cl = threadIdx.x & (CF_COLS - 1), g = threadIdx.x / CF_COLS;
+    const int c = blockIdx.x * CF_COLS + cl;
     double s = 0.0;
     if (c < ncol)
-        for (int b = g; b < nblk; b += FIN_GROUPS) s += (double)partial[(size_t)b * ncol + c];
-    red[g][cl] = s;
+        for (int b = g; b < nblk; b += CF_GROUPS) s += (double)partial[(size_t)b * ncol + c];
+#pragma unroll
+    for (int o = CF_COLS; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) < CF_COLS) red[threadIdx.x >> 6][threadIdx.x & 63] = s;
     __syncthreads();
     if (g != 0 || c >= ncol) return;
-    for (int gg = 1; gg < FIN_GROUPS; ++gg) s += red[gg][cl];
+    s = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
     float* dst = (c < split_at) ? (out0 + c) : (out1 + (c - split_at));
     *dst = accumulate ? (*dst + (float)s) : (float)s;
 }
@@ -556,7 +557,7 @@ static int ln_bwd_launch(const TDY* dy, const float* x, const float* mean, const
         default: DS6G_CHECK_ARG(!"LayerNorm width must be 64/128/256/512");
     }
     DS6G_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_finalize_kernel, dim3(cdiv(2 * C, FIN_COLS)), dim3(256), 0, st, partial, nblk, 2 * C, dgamma,
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(cdiv(2 * C, 4)), dim3(256), 0, st, partial, nblk, 2 * C, dgamma,
                        dbeta, C, accumulate_param_grads);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
@@ -719,7 +720,7 @@ int ds6g_colsum(const float* x, long M, int C, float* out, int accumulate, void*
     float* partial = (float*)ws;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), lds, (hipStream_t)stream, x, M, C, rpb, partial);
     DS6G_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_finalize_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, out,
+    hipLaunchKernelGGL(col_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, out,
                        out, C, accumulate);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
