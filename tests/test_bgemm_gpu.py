@@ -334,3 +334,42 @@ def test_bf16_stored_attention_fwd_bwd(dev, B, T, nh, hd):
     for a, b in zip((dkqv[:, C:2 * C], dkqv[:, :C], dkqv[:, 2 * C:]), ref):
         assert rel(a, b.double().cpu()) < 1e-2
     assert rel(od16, od32.double().cpu()) < 1e-2      # same (seed, offset) -> same dropout mask
+
+
+@pytest.mark.parametrize("hd", [16, 32, 64, 128])
+def test_bf16_stored_attention_with_dropout_at_bench_batch(dev, hd):
+    """The bf16 configuration bench.py times runs attn_drop 0.1 at B = 12 too.  All-bf16 attention forward and backward (dS
+    hand-over; the four-decisions-per-hash mask with its DPP quad broadcasts in the bf16 instantiations, key-split forward,
+    query-split dK/dV at 1 536 workgroups) against an fp64 reference on the same bf16-rounded q / k / v / dO with the keep mask
+    rebuilt on the CPU (tests/test_bench_shapes_gpu.py::_keep_mask).  Bar: 1e-2 of the largest value (builder-declared: the
+    kernel rounds P and dS to bf16 for the second products; measured 2.3e-3 ... 5.2e-3); a wrong mask offset in any split
+    decorrelates ~19 % of the probabilities: O(0.3)."""
+    from deepsense6g_tii_amd import ops
+    from deepsense6g_tii_amd._lib import lib
+    from tests.test_bench_shapes_gpu import _keep_mask, _threads
+    B, T, nh, p = 12, 962, 4, 0.1
+    C = nh * hd
+    torch.set_num_threads(_threads())
+    g = torch.Generator().manual_seed(1000 + hd)
+    kqv = r16(torch.randn(B * T, 3 * C, generator=g)).cuda()
+    k, q, v = kqv[:, :C], kqv[:, C:2 * C], kqv[:, 2 * C:]
+    do = r16(torch.randn(B * T, C, generator=g)).cuda()
+    seed, off = 0xC0FFEE ^ (hd << 35), (5 << 40) + 91 * 1024
+    ws = ops.Workspace(dev, int(lib().attention_workspace_bytes(B, T, nh, hd, C)) + (64 << 20))
+    o16, lse = ops.attention_fwd_bf16(q, k, v, B, T, nh, ws, p, seed, off)
+    dkqv = torch.full((B * T, 3 * C), float("nan"), dtype=BF, device=dev)
+    ops.attention_bwd_bf16io(q, k, v, o16, do, lse, B, T, nh, ws, p, seed, off, out=(dkqv[:, C:2 * C], dkqv[:, :C], dkqv[:, 2 * C:]))
+    torch.cuda.synchronize()
+    assert torch.isfinite(dkqv.float()).all()
+    qd, kd, vd = (t.double().cpu().requires_grad_(True) for t in (q, k, v))
+    heads = lambda t: t.view(B, T, nh, hd).transpose(1, 2)  # noqa: E731
+    att = torch.softmax((heads(qd) @ heads(kd).transpose(-2, -1)) / math.sqrt(hd), dim=-1)
+    att = att * _keep_mask(seed, off, (B, nh, T, T), p, dtype=torch.float64)
+    oref = (att @ heads(vd)).transpose(1, 2).reshape(B * T, C)
+    oref.backward(do.double().cpu())
+
+    def rel(a, b):
+        return ((a.double().cpu() - b).abs().max() / b.abs().max()).item()
+    errs = dict(o=rel(o16, oref.detach()), dq=rel(dkqv[:, C:2 * C], qd.grad), dk=rel(dkqv[:, :C], kd.grad), dv=rel(dkqv[:, 2 * C:], vd.grad))
+    print("bf16-stored attention with dropout at B = 12, errors", hd, errs)
+    assert max(errs.values()) < 1e-2, errs      # measured 2.3e-3 ... 5.2e-3
