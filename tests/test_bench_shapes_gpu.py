@@ -546,6 +546,35 @@ def test_timed_configuration_bs12_dropout_all_gradients_vs_fp64_yardstick(run_b1
     _all_gradients_vs_fp64(run_b12_drop_f64)
 
 
+def test_timed_configuration_bs12_dropout_in_the_fp32_grade_split_mode(dev, run_b12_drop_f64):
+    """`other_modes.f32x6` of the bench line (three-way bf16 split, six products: fp32-grade, faster than the exact fp32 MFMA on
+    this part) at the configuration the bench times: the same weights, inputs, seed and salt as run_b12_drop, so the HIP path
+    draws the very masks the cached oracle runs used.  Logits and loss against the fp32 oracle at the exact path's 1e-3 bar,
+    ALL gradient tensors against the fp64 run with the fp32 oracle as yardstick - the bars of the exact path, unchanged."""
+    from deepsense6g_tii_amd import ops
+    from deepsense6g_tii_amd.model import GlobalConfig, TransFuser
+    st = run_b12_drop_f64
+    imgs, lids, rads, gps, target = st["inputs"]
+    ops.set_compute_mode("f32x6")
+    try:
+        model = TransFuser(GlobalConfig(), dev)
+        model.load_state_dict(st["sd"], strict=True)
+        model.train()
+        loss, logits = model.train_step_loss(imgs, lids, rads, gps, target)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_compute_mode("f32")
+    assert (model._seed, model._salt_host) == (st["book"].seed, st["book"].salt) and model._drop_counter == st["sites_counted"]
+    e_logits = rel(logits, st["ologits"])
+    print(f"f32x6 at bs 12 with dropout: logits {e_logits:.2e} (exact path: {rel(st['logits'], st['ologits']):.2e}), "
+          f"loss {float(loss):.6f} vs {st['oloss']:.6f}")
+    assert e_logits < TOL and abs(float(loss) - st["oloss"]) < TOL * abs(st["oloss"])
+    grads = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
+    del model
+    torch.cuda.empty_cache()
+    _all_gradients_vs_fp64(dict(grads=grads, ograds=st["ograds"], grads64=st["grads64"]))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def test_config1_image_only_zeroed_modalities(dev):
     """BASELINE configs[1]: LiDAR / radar inputs zeroed, bs = 12.  The all-zero stems give exactly zero-variance
