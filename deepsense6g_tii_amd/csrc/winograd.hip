@@ -721,6 +721,7 @@ struct WinoWgradParams {
     int N, H, W, C, K, TH, TW;
     int tiles_total, tiles_per_split;  // tiles_per_split is a multiple of 16
     unsigned x_bytes, dy_bytes;
+    int xcd;             // XCD-contiguous workgroup order (DS6G_WW_XCD=0 switches it off)
 };
 
 constexpr int WW_T = 16;   // tiles per chunk (MFMA reduction depth)
@@ -732,9 +733,22 @@ __global__ __launch_bounds__(256, 2) void winograd_wgrad_kernel(const WinoWgradP
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, khalf = lane >> 5;
     const int cblocks = p.C / WW_CB;
-    const int k0 = (blockIdx.x / cblocks) * WW_KB, c0 = (blockIdx.x % cblocks) * WW_CB;
-    const int ri = blockIdx.y;          // row i of the position grid
-    const int split = blockIdx.z;
+    // XCD-aware order (round 3): the hardware deals workgroups round-robin over the 8 XCDs in dispatch order (x fastest, then
+    // y, then z); remapped so that every XCD walks a CONTIGUOUS run of (split, row, channel-block pair) ids, channel-block pair
+    // fastest: the K/64 x C/64 workgroups of one (split, row i) - which read the same two patch rows of the same x tiles and the
+    // same dy tiles, each a different channel slice pair - meet in one L2 instead of eight
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
+    if (p.xcd) {
+        const int gx = (int)gridDim.x, nwg = gx * 4 * (int)gridDim.z, orig = bx + gx * (by + 4 * bz);
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+        const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+        bx = lin % gx;
+        by = (lin / gx) & 3;
+        bz = lin / (4 * gx);
+    }
+    const int k0 = (bx / cblocks) * WW_KB, c0 = (bx % cblocks) * WW_CB;
+    const int ri = by;          // row i of the position grid
+    const int split = bz;
     const int tbeg = split * p.tiles_per_split;
     const int tend = min(p.tiles_total, tbeg + p.tiles_per_split);
     const int nchunks = (tend - tbeg + WW_T - 1) / WW_T;
@@ -1118,6 +1132,7 @@ int ds6g_conv3x3_winograd_wgrad(const float* x, const float* dy, float* dw, int 
     const int cps = (int)((chunks + splits - 1) / splits);
     p.tiles_per_split = cps * WW_T;
     splits = (chunks + cps - 1) / cps;
+    { static const int xcd_env = [] { const char* e = getenv("DS6G_WW_XCD"); return e ? atoi(e) : 1; }(); p.xcd = xcd_env; }
     void* rec = ds6g_prof_open(20001, 2.0 * N * H * W * (double)K * 9.0 * C, (hipStream_t)stream);
     hipLaunchKernelGGL(winograd_wgrad_kernel, dim3((unsigned)((K / WW_KB) * (C / WW_CB)), 4, (unsigned)splits), dim3(256), 0,
                        (hipStream_t)stream, p);
