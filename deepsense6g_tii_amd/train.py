@@ -151,6 +151,12 @@ class FusedAdamW:
                              ops._stream())
 
     def zero_grad(self, set_to_none=True):
+        if self._began:
+            # enable_overlap(): a backward walk already advanced this step's scalars and updated its buckets, and no step()
+            # followed (backward == a partial step while overlap is on).  Starting the next iteration on stale scalars would
+            # silently skip an _advance_state(): refuse instead.
+            raise RuntimeError("FusedAdamW.zero_grad(): a backward ran under enable_overlap() without a following step(); "
+                               "with overlap on, backward already applies the update bucket by bucket - call step() after it")
         if set_to_none:
             for _, p in getattr(self.model, "_plist", None) or self.model.named_parameters():
                 p.grad = None
@@ -401,6 +407,9 @@ class CapturedTrainStep:
 
     def __init__(self, model, optimizer, batch, ema=None, warmup=2):
         if model.grad_ready_hook is not None:
+            if getattr(optimizer, "_overlap", None) is not None:
+                raise RuntimeError("CapturedTrainStep: FusedAdamW.enable_overlap() is active (per-bucket updates issued from "
+                                   "the backward walk's gradient hook); capture a step without optimizer overlap")
             raise RuntimeError("CapturedTrainStep: data-parallel training runs eagerly (bucketed all-reduce)")
         self.model, self.optimizer, self.ema = model, optimizer, ema
         dev = model.device
@@ -436,6 +445,9 @@ class CapturedTrainStep:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         del snap
+        # the restore put the device lr slot back to its pre-warm-up value (0 for a fresh optimizer) while the host cache
+        # still says "synced": invalidate it, or the captured AdamW would replay with lr 0 until the schedule changes lr
+        optimizer._dev_lr = None
         optimizer.sync_lr()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):

@@ -153,12 +153,15 @@ def test_training_trajectory_tracks_cpu_oracle(dev):
     assert err < 5e-2, err
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
-def test_captured_train_step_is_bit_identical_to_eager(dev, mode):
+@pytest.mark.parametrize("mode,lr_factor", [("f32", 0.5), ("bf16", 0.5), ("f32", 1.0)])
+def test_captured_train_step_is_bit_identical_to_eager(dev, mode, lr_factor):
     """CapturedTrainStep: the whole iteration (forward, focal loss, backward, AdamW + EMA; dropout 0.1; three trunk streams
     and the weight-gradient companion stream) replayed from ONE HIP graph must leave the same parameters, optimizer state,
     BatchNorm buffers and loss as the eager iterations, bit for bit - including fresh dropout masks on every replay (the
-    salt lives in device memory) and the bias corrections of the right step (optimizer scalars in device memory)."""
+    salt lives in device memory) and the bias corrections of the right step (optimizer scalars in device memory).
+    lr_factor 1.0 is the constant-lr case (a fresh optimizer -> CapturedTrainStep -> step() with param_groups['lr'] never
+    touched): the undone warm-up must not leave the device lr slot at its pre-warm-up 0
+     - the parameters have to move, exactly as the eager run moves them."""
     from deepsense6g_tii_amd import ops
     from deepsense6g_tii_amd.model import GlobalConfig, TransFuser
     from deepsense6g_tii_amd.train import EMA, CapturedTrainStep, FusedAdamW, train_iteration
@@ -188,23 +191,28 @@ def test_captured_train_step_is_bit_identical_to_eager(dev, mode):
                 with pytest.raises(ValueError):
                     CapturedTrainStep(model, opt, batches[0], ema, warmup=0)
                 for b in batches[1:]:
-                    opt.param_groups[0]["lr"] *= 0.5          # a schedule change between replays reaches the graph
+                    if lr_factor != 1.0:
+                        opt.param_groups[0]["lr"] *= lr_factor    # a schedule change between replays reaches the graph
                     loss, _ = step(b)
                     losses.append(float(loss))
                 assert step.steps_replayed == 2
+                assert not torch.equal(model.flat_parameters()[0], before[0]), "replayed AdamW did not move the parameters"
             else:
                 for b in batches[1:]:
-                    opt.param_groups[0]["lr"] *= 0.5
+                    if lr_factor != 1.0:
+                        opt.param_groups[0]["lr"] *= lr_factor
                     loss, _ = train_iteration(model, opt, b, ema)
                     losses.append(float(loss))
             torch.cuda.synchronize()
+            assert float(opt._dev[0]) == float(torch.tensor(opt.param_groups[0]["lr"], dtype=torch.float32))
             runs.append(dict(p=model.flat_parameters()[0].clone(), m=opt.m.clone(), v=opt.v.clone(), sh=opt.shadow.clone(),
+                             dev=opt._dev.clone().view(torch.int32),
                              bufs=[b.clone() for b in model.buffers()], losses=losses, steps=opt.step_count,
                              salt=(model._salt_host, int(model._salt.item()))))
         a, b = runs
         assert a["losses"] == b["losses"] and a["steps"] == b["steps"] == 2
         assert a["salt"] == b["salt"] and a["salt"][0] == a["salt"][1]
-        for k in ("p", "m", "v", "sh"):
+        for k in ("p", "m", "v", "sh", "dev"):
             assert torch.equal(a[k], b[k]), k
         for x, y in zip(a["bufs"], b["bufs"]):
             assert torch.equal(x, y)
