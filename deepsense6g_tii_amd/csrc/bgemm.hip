@@ -29,6 +29,9 @@ void ds6g_prof_close(void* rec, hipStream_t st);
 // igemm.hip: sums split-K slabs (weight gradient + optional bias-gradient tail) into the fp32 gradient
 int ds6g_internal_splitk_reduce(const float* ws, float* dw, long n4, float* dbias, long m4, int splits, size_t stride,
                                 int accumulate, int accumulate_b, hipStream_t st);
+// norm.hip: mean / invstd (+ running statistics) from nblk row-block partials [nblk][2][C] (fp64)
+int ds6g_internal_bn_stats_finalize(const double* partial, int nblk, long M, int C, float eps, float momentum, float* mean,
+                                    float* invstd, float* running_mean, float* running_var, hipStream_t st);
 
 namespace {
 
@@ -61,12 +64,17 @@ struct BgemmParams {
     int tiles_n;
     int wg_rows;          // WGRAD: 0 = a k-tile of 64 pixels stays inside one output row; else output rows per k-tile
     int want_colsum;
+    int xcd_splits;       // WGRAD: every XCD walks a contiguous run of (split, tile) pairs, tile fastest (see the kernel)
     unsigned a_bytes, b_bytes;
     // DGRAD of a strided conv runs per input-pixel parity class (blockIdx.y when nclass > 1, parameters derived in the
     // kernel): pixels h = h0 + hstep*hh (hh < Hs), taps r = r0 + rstep*ri (ri < nr) - only the taps that hit a real
     // output pixel, no structural zeros (as igemm.hip)
     int nclass;
     int h0, hstep, Hs, w0, wstep, Ws, r0, rstep, nr, s0, sstep, ns;
+    // FWD, bf16 output, no epilogue: per-tile-row column sums / sums of squares of the STORED (rounded) tile for the
+    // train-mode BatchNorm that follows the conv - partial[tile_m][0][col], partial[tile_m][1][col] (fp64, the layout
+    // bn_stats_finalize_kernel reads), so the separate statistics pass over the conv output is not needed
+    double* bn_partial;
 };
 
 __device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(unsigned long)(lds_void*)p; }
@@ -101,15 +109,23 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, khalf = lane >> 5;
-    int wg;
-    {   // XCD-aware tile order (bijective for any grid), as igemm.hip
+    int wg, split = blockIdx.z;
+    if (MODE == B_WGRAD && p.xcd_splits) {
+        // the hardware deals workgroups to the 8 XCDs (private L2s) in dispatch order, x fastest, then z.  The tiles of ONE
+        // split read the same dy rows and the same / overlapping x rows: give every XCD a contiguous run of (split, tile)
+        // pairs, tile fastest, so that a split's operands are fetched by one L2 (two at a run boundary) instead of eight
+        const int nwg = gridDim.x * gridDim.z, orig = blockIdx.x + gridDim.x * blockIdx.z;
+        const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        split = lin / (int)gridDim.x;
+        wg = lin - split * (int)gridDim.x;
+    } else {   // XCD-aware tile order (bijective for any grid), as igemm.hip
         const int nwg = gridDim.x, orig = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
     const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int split = blockIdx.z;
     const int kbegin = (MODE == B_WGRAD) ? split * p.k_per_split : 0;
     const int kend = (MODE == B_WGRAD) ? min(p.Kg, kbegin + p.k_per_split) : p.Kg;
     const int nk = (kend - kbegin + BK - 1) / BK;
@@ -429,6 +445,10 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
         __bf16* outp = reinterpret_cast<__bf16*>(p.out);
         constexpr int PR = BM / 2, PC = BN / 2;
         __bf16* patch = reinterpret_cast<__bf16*>(lds) + wave * PR * PC;
+        const bool stats = !EPI && MODE == B_FWD && p.bn_partial != nullptr;
+        float cs[TN], cq[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) cs[j] = cq[j] = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -452,8 +472,34 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
                         }
                         if (p.drop_thr) v = ds6g_keep(p.seed, p.seed_off + (uint64_t)e, p.drop_thr) ? v * p.drop_scale : 0.f;
                     }
-                    patch[(i * 32 + 4 * khalf + dr) * PC + j * 32 + l31] = (__bf16)v;
+                    const __bf16 vb = (__bf16)v;
+                    patch[(i * 32 + 4 * khalf + dr) * PC + j * 32 + l31] = vb;
+                    if (!EPI && MODE == B_FWD) {   // rows >= Mg are products of zero-filled im2col rows: they add 0
+                        const float vr = (float)vb;
+                        cs[j] += vr;
+                        cq[j] += vr * vr;
+                    }
                 }
+            }
+        }
+        if (stats) {
+            // column sums of the tile: lane halves (rows 4 khalf + ...) by a cross-lane add, the two row-waves through LDS
+            // (above the four output patches: 4 * PR * PC * 2 <= half of the staging buffers)
+            float* red = reinterpret_cast<float*>(lds + 4 * PR * PC * 2);   // [2 (wm)][2 (sum, sumsq)][BN]
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                cs[j] += __shfl_xor(cs[j], 32, 64);
+                cq[j] += __shfl_xor(cq[j], 32, 64);
+                if (khalf == 0) {
+                    red[(wm * 2 + 0) * BN + wn * PC + j * 32 + l31] = cs[j];
+                    red[(wm * 2 + 1) * BN + wn * PC + j * 32 + l31] = cq[j];
+                }
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.Ng) {
+                double* dst = p.bn_partial + (size_t)tile_m * 2 * p.Ng + n0 + tid;
+                dst[0] = (double)red[tid] + (double)red[2 * BN + tid];
+                dst[p.Ng] = (double)red[BN + tid] + (double)red[3 * BN + tid];
             }
         }
         // wave-private patch: the wave's own LDS writes are ordered before its reads by the compiler's lgkmcnt waits
@@ -486,6 +532,13 @@ int g_bg_min_blocks = 200;
 // win - convs peak at ~384, the GPT linears at ~512; 1024 costs 15-25 %, 2048+ up to 2x through the slab reduction)
 int g_bg_wgrad_target = 0;
 int g_bg_force_tile = -1;   // tuning experiments (env DS6G_BG_TILE / DS6G_BG_MINBLOCKS, read once)
+// wgrad (split, tile) -> XCD mapping (env DS6G_BG_WXCD): 0 plain (tiles of each split dealt XCD-contiguously), 1 (default)
+// contiguous (split, tile) runs where they measured faster (tools/bench_bwgrad.py, N = 60: convs with <= 24 output tiles -
+// 64x64x64 75 -> 57 us / 499 -> 72 MB read, 32x32x128 45 -> 35 us / 247 -> 37 MB, the stride-2 layers 31 -> 25 us; the
+// 36 .. 144-tile layers lose 1 - 2 us although their traffic falls 2 - 4x - and the large linears whose workgroup count is a
+// multiple of 8, i.e. whole splits per XCD: fc1 / fc2 / proj of stage 4 44.8 -> 40.2 us, 142 - 213 -> 59 MB), 2 every conv,
+// 3 everything
+int g_bg_wxcd = 1;
 void bg_env() {
     static bool done = false;
     if (done) return;
@@ -493,6 +546,7 @@ void bg_env() {
     if (const char* e = getenv("DS6G_BG_TILE")) g_bg_force_tile = atoi(e);
     if (const char* e = getenv("DS6G_BG_MINBLOCKS")) g_bg_min_blocks = atoi(e);
     if (const char* e = getenv("DS6G_BG_WTARGET")) g_bg_wgrad_target = atoi(e);
+    if (const char* e = getenv("DS6G_BG_WXCD")) g_bg_wxcd = atoi(e);
 }
 
 void fill_conv(BgemmParams& p, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
@@ -567,6 +621,11 @@ int run_wgrad(BgemmParams& p, float* dw, int accumulate, float* dbias, float* ws
     p.k_per_split = kps;
     p.split_stride = (size_t)slab_elems;
     p.want_colsum = dbias != nullptr;
+    {
+        const bool linear = p.N * p.Ho == 1;
+        const bool pays = linear ? ((tiles * splits) % 8 == 0 && (long)p.Mg * p.Ng >= 512L * 512) : tiles <= 24;
+        p.xcd_splits = (splits >= 2 && ((g_bg_wxcd == 1 && pays) || (g_bg_wxcd == 2 && (!linear || pays)) || g_bg_wxcd >= 3)) ? 1 : 0;
+    }
     if (splits == 1 && !accumulate && !dbias) {
         p.out = dw;
         return launch_bgemm<B_WGRAD>(p, 0, 1, tile, st);
@@ -602,6 +661,33 @@ int ds6g_bf16_conv2d_fwd(const void* x, const void* w, void* y, int out16, int N
     p.Mg = N * p.Ho * p.Wo; p.Ng = K; p.Kg = R * S * C;
     return launch_bgemm<B_FWD>(p, out16, 1, pick_tile(p.Mg, p.Ng, 1), (hipStream_t)stream);
 }
+
+// y = conv(x, w) as above with a bf16 output, plus the train-mode BatchNorm statistics of y (batch mean / invstd, running
+// statistics updated in place when given) from per-tile column partials written by the conv's epilogue: the statistics are
+// those of the STORED bf16 tensor (what ds6g_bf16_bn_stats would compute), without a pass over it.
+// ws: >= ds6g_bf16_conv_bnstats_workspace_bytes(N * Ho * Wo, K).
+int ds6g_bf16_conv2d_fwd_bnstats(const void* x, const void* w, void* y, int N, int H, int W, int C, int K, int R, int S,
+                                 int stride, int pad, float eps, float momentum, float* mean, float* invstd,
+                                 float* running_mean, float* running_var, void* ws, size_t ws_bytes, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && w && y && mean && invstd && ws && C % BK == 0 && K % 8 == 0 && N > 0);
+    BgemmParams p;
+    fill_conv(p, N, H, W, C, K, R, S, stride, pad);
+    DS6G_CHECK_ARG(sizes_ok(p));
+    p.a_src = (const __bf16*)x; p.b_src = (const __bf16*)w; p.out = y;
+    p.a_bytes = (unsigned)((size_t)N * H * W * C * 2); p.b_bytes = (unsigned)((size_t)K * R * S * C * 2);
+    p.Mg = N * p.Ho * p.Wo; p.Ng = K; p.Kg = R * S * C;
+    const int tile = pick_tile(p.Mg, p.Ng, 1);
+    const int nblk = cdiv(p.Mg, tile == 0 ? 128 : 64);
+    DS6G_CHECK_ARG(ws_bytes >= (size_t)nblk * 2 * K * sizeof(double));
+    p.bn_partial = (double*)ws;
+    const int rc = launch_bgemm<B_FWD>(p, 1, 1, tile, (hipStream_t)stream);
+    if (rc) return rc;
+    return ds6g_internal_bn_stats_finalize(p.bn_partial, nblk, (long)p.Mg, K, eps, momentum, mean, invstd, running_mean,
+                                           running_var, (hipStream_t)stream);
+}
+
+size_t ds6g_bf16_conv_bnstats_workspace_bytes(long M, int K) { return (size_t)cdiv(M, 64) * 2 * K * sizeof(double); }
 
 // dx (+)= conv^T(dy, w): dy bf16, w bf16, dx bf16 / fp32.  K % 64 == 0, C % 8 == 0; stride 1, or 2 with even H, W (the four
 // input-pixel parity classes of a stride-2 layer run as one launch).

@@ -563,6 +563,15 @@ static int ln_bwd_launch(const TDY* dy, const float* x, const float* mean, const
     return DS6G_OK;
 }
 
+// bgemm.hip: the conv epilogue wrote the partials (ds6g_bf16_conv2d_fwd_bnstats)
+int ds6g_internal_bn_stats_finalize(const double* partial, int nblk, long M, int C, float eps, float momentum, float* mean,
+                                    float* invstd, float* running_mean, float* running_var, hipStream_t st) {
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, BNF_COLS)), dim3(256), 0, st, partial, nblk, M, C, eps,
+                       momentum, mean, invstd, running_mean, running_var);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
 extern "C" {
 
 size_t ds6g_bn_workspace_bytes(long M, int C) {

@@ -22,6 +22,7 @@ train2_seq.py:326-333).
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 from torch import nn
@@ -223,6 +224,8 @@ class TransFuser(nn.Module):
         self.overlap_wgrad = True  # GPT-stage weight gradients on a second stream, overlapping the dgrad / attention chain
         self._wg_map, self._wg_used, self._wg_keep = {}, {}, []
         self.overlap_wgrad_trunks = False  # measured: no gain on top of the three concurrent trunk streams
+        # bf16 configuration: train-mode BatchNorm statistics come out of the conv's epilogue (ds6g_bf16_conv2d_fwd_bnstats)
+        self.fuse_bn_stats16 = os.environ.get("DS6G_FUSE_BN_STATS16", "1") != "0"
         self._fold_now = False
         self._recording = False
         self.use_winograd = True  # 3x3 / stride-1 convs (forward and data gradient) as Winograd F(2x2, 3x3) in fp32 mode
@@ -699,6 +702,22 @@ class TransFuser(nn.Module):
         """BasicBlock on bf16-stored feature maps: convs on csrc/bgemm.hip (direct implicit GEMM, bf16 tiles, bf16 weight
         shadow), BatchNorm reading / writing bf16 with fp32 statistics.  Same tape layout as _block_fwd."""
         K = blk.conv1.out_channels
+        if train and self.fuse_bn_stats16:
+            # train mode: the conv's epilogue emits the BatchNorm statistics of its (stored) output - no statistics pass
+            def conv_bn(inp, conv, bn, R, stride, pad, relu, residual):
+                stats = torch.empty(2, K, dtype=F32, device=inp.device)
+                c = ops.bf16_conv2d_fwd_bnstats(inp, self._w16(conv.weight), K, R, R, stride, pad, stats[0], stats[1],
+                                                bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self._ws, bn.eps,
+                                                bn.momentum)
+                y = ops.bf16_bn_apply(c, stats[0], stats[1], self._w(bn.weight), self._w(bn.bias), relu, residual)
+                return c, y, (stats[0], stats[1])
+            c1, a1, s1 = conv_bn(x, blk.conv1, blk.bn1, 3, blk.stride, 1, True, None)
+            if blk.downsample is not None:
+                cd, idn, sd = conv_bn(x, blk.downsample[0], blk.downsample[1], 1, blk.stride, 0, False, None)
+            else:
+                cd, sd, idn = None, None, x
+            c2, out, s2 = conv_bn(a1, blk.conv2, blk.bn2, 3, 1, 1, True, idn)
+            return out, (x, c1, a1, s1, c2, s2, cd, sd, out, None, None)
         c1 = ops.bf16_conv2d_fwd(x, self._w16(blk.conv1.weight), K, 3, 3, blk.stride, 1)
         a1, s1 = self._bn_fwd16(blk.bn1, c1, True, None, train)
         c2 = ops.bf16_conv2d_fwd(a1, self._w16(blk.conv2.weight), K, 3, 3, 1, 1)

@@ -409,6 +409,20 @@ def bf16_conv2d_fwd(x, w16_ptr, K, R, S, stride, pad, out16=True):
     return y
 
 
+def bf16_conv2d_fwd_bnstats(x, w16_ptr, K, R, S, stride, pad, mean, invstd, rm_ptr, rv_ptr, ws: Workspace, eps=1e-5,
+                            momentum=0.1):
+    """y = conv(x, w) (bf16) and the train-mode BatchNorm statistics of y from the conv's own epilogue (no pass over y)"""
+    N, H, W, C = x.shape
+    _chk16(x)
+    _chk(mean, K)
+    _chk(invstd, K)
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    y = torch.empty((N, Ho, Wo, K), dtype=BF16, device=x.device)
+    lib().bf16_conv2d_fwd_bnstats(_p(x), w16_ptr, _p(y), N, H, W, C, K, R, S, stride, pad, eps, momentum, _p(mean),
+                                  _p(invstd), rm_ptr, rv_ptr, ws.ptr, ws.nbytes, _stream())
+    return y
+
+
 def bf16_conv2d_dgrad(dy, w16_ptr, x_shape, R, S, stride, pad, out16=True, out=None, accumulate=False):
     N, H, W, C = x_shape
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)

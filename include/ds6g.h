@@ -125,6 +125,14 @@ int ds6g_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, 
  * other a multiple of 8; dgrad: stride 1, or 2 with even H, W; wgrad: Wo % 64 == 0, or 64 % Wo == 0 with Ho % (64 / Wo) == 0, or a Linear. */
 int ds6g_bf16_conv2d_fwd(const void* x, const void* w, void* y, int out16, int N, int H, int W, int C, int K, int R, int S,
                          int stride, int pad, void* stream);
+/* conv (bf16 output) + the train-mode BatchNorm statistics of its output in one call (the BasicBlock pairs conv1 / bn1,
+ * conv2 / bn2, downsample.0 / .1 of torchvision's ResNet, model2_seq.py:510-512,528-530,546-548,565-567): the conv's epilogue
+ * writes per-tile column sums / sums of squares of the STORED bf16 tile, a small finalize kernel turns them into mean /
+ * invstd and updates the running statistics - what ds6g_bf16_bn_stats(y) computes, without its pass over y. */
+size_t ds6g_bf16_conv_bnstats_workspace_bytes(long M, int K);
+int ds6g_bf16_conv2d_fwd_bnstats(const void* x, const void* w, void* y, int N, int H, int W, int C, int K, int R, int S,
+                                 int stride, int pad, float eps, float momentum, float* mean, float* invstd,
+                                 float* running_mean, float* running_var, void* ws, size_t ws_bytes, void* stream);
 int ds6g_bf16_conv2d_dgrad(const void* dy, const void* w, void* dx, int out16, int N, int H, int W, int C, int K, int R,
                            int S, int stride, int pad, int accumulate, void* stream);
 int ds6g_bf16_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
