@@ -10,8 +10,9 @@ work of CARLA_Data.__getitem__, /root/reference/data2_seq.py:42-173: numpy resta
 
 Pinned: `lidar_bev` is checked against the reference's own function (imported with stubs for the absent
 open3d / utm / cv2 / torchvision modules) by tests/golden/make_golden_data.py -> tests/golden/data_golden.npz.
-The soft target and the image step live inline in `__getitem__` (needs the dataset on disk) and are restated from
-the source text; they are pinned by the closed forms they spell out (scipy.stats.norm.pdf, np.transpose).
+The soft target, the flip augmentation of every modality and the frame / radar tensor layout live inline in `__getitem__`:
+`getitem()` below restates them, and tests/golden/make_golden_getitem.py runs the reference's own `__getitem__` on the same
+synthetic in-memory files (its three file readers pointed at a table) -> tests/golden/getitem_golden.npz, max abs diff 0.0.
 """
 from __future__ import annotations
 
@@ -105,3 +106,49 @@ def make_cloud(n: int, seed: int, xbins=None, ybins=None):
     pts[k + 2 * e + 2] = (np.nextafter(xbins[-1], np.inf), 0.0, 0.0)  # just outside
     pts[k + 2 * e + 3] = (np.nan, 0.0, 0.0)
     return pts
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# one whole sample, as CARLA_Data.__getitem__ (data2_seq.py:42-173) builds it from decoded files
+def make_getitem_files(seed: int, scen: int, beam1: int, custom_fov: bool):
+    """synthetic decoded "files" of one 5-frame sample -> (files: path -> array, dataframe columns, gps (2, 2)).
+    Paths follow the reference's rewriting rules for augment = {camera: 1, lidar: 0, radar: 0} (data2_seq.py:64-87)."""
+    rng = np.random.default_rng(seed)
+    base = f"scenario{scen}/unit1/"
+    files, frame = {}, {"unit1_beam": [beam1]}
+    for k in range(1, 6):
+        frame[f"unit1_rgb_{k}"] = [base + f"camera_data/image_{k}.jpg"]
+        frame[f"unit1_lidar_{k}"] = [base + f"lidar_data/cloud_{k}.ply"]
+        frame[f"unit1_radar_{k}"] = [base + f"radar_data/radar_{k}.npy"]
+        files[base + f"camera_data_aug/image_{k}_1.jpg"] = rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
+        xb, yb = fov_edges(base, custom_fov)
+        files[base + f"lidar_data/cloud_{k}.ply"] = make_cloud(4000 + 100 * k, seed * 10 + k, xb, yb)
+        files[base + f"radar_data_ang/radar_{k}.npy"] = rng.random((256, 256), dtype=np.float32)
+        files[base + f"radar_data_vel/radar_{k}.npy"] = rng.standard_normal((256, 256), dtype=np.float32)
+    gps = rng.uniform(-1, 1, (2, 2))
+    return files, frame, gps
+
+
+def getitem(seed: int, scen: int, beam1: int, flip: bool, custom_fov: bool, add_velocity: int):
+    """the oracle's restatement of one sample: fronts 5 x (3, 256, 256) uint8 (HWC -> CHW view, :147), radars 5 x (1 | 2,
+    256, 256) float32 (angle [+ velocity] maps stacked, :148-154), lidars 5 x (1, 256, 256) float64 (:155-159), gps (2, 2)
+    with the second coordinate negated under flip (:49-50), the Gaussian soft beam target and the beam index (:160-171)."""
+    files, frame, gps = make_getitem_files(seed, scen, beam1, custom_fov)
+    base = f"scenario{scen}/unit1/"
+    out = dict(fronts=[], radars=[], lidars=[])
+    g = gps.copy()
+    if flip:
+        g[:, 1] = -g[:, 1]
+    out["gps"] = g
+    for k in range(1, 6):
+        img = files[base + f"camera_data_aug/image_{k}_1.jpg"]
+        ang = files[base + f"radar_data_ang/radar_{k}.npy"]
+        vel = files[base + f"radar_data_vel/radar_{k}.npy"]
+        if flip:
+            img, ang, vel = (np.ascontiguousarray(np.flip(a, 1)) for a in (img, ang, vel))
+        out["fronts"].append(np.transpose(img, (2, 0, 1)))
+        out["radars"].append(np.concatenate([ang[None], vel[None]], 0) if add_velocity else ang[None])
+        path = base + f"lidar_data/cloud_{k}.ply"
+        out["lidars"].append(lidar_bev(files[path], path, custom_fov, flip))
+    out["beam"], out["beamidx"] = soft_beam_target(beam1 - 1, flip)
+    return out

@@ -247,6 +247,55 @@ def test_linear_kernels_at_bench_rows(dev, N, K):
 @pytest.mark.parametrize("pdrop", [0.0, 0.1], ids=["nodrop", "drop0.1"])
 @pytest.mark.parametrize("hd", [16, 32, 64, 128])
 def test_attention_at_bench_batch(dev, hd, pdrop):
+    _attention_case(dev, hd, pdrop, B=12, T=962)
+
+
+@pytest.mark.parametrize("hd,pdrop,bf16", [(16, 0.1, False), (32, 0.0, False), (64, 0.1, False), (128, 0.1, False),
+                                           (64, 0.1, True), (128, 0.1, True)])
+def test_attention_at_1922_tokens(dev, hd, pdrop, bf16):
+    """the 30 -> 5 variant's sequence (seq_len 10 => T = 1922 = 60 * 32 + 2 tokens, /root/reference/model2_seq_30to5.py:188)
+    at the kernel level, B = 3: forward and every backward form against torch autograd with CPU-rebuilt masks (fp32
+    storage), and the bf16-stored kernels against the same reference on bf16-rounded operands."""
+    if bf16:
+        _attention_case_bf16(dev, hd, pdrop, B=3, T=1922)
+    else:
+        _attention_case(dev, hd, pdrop, B=3, T=1922)
+
+
+def _attention_case_bf16(dev, hd, pdrop, B, T):
+    from deepsense6g_tii_amd import ops
+    from deepsense6g_tii_amd._lib import lib
+    nh = 4
+    C = nh * hd
+    BF = torch.bfloat16
+    torch.set_num_threads(_threads())
+    g = torch.Generator().manual_seed(hd + 1)
+    q, k, v = (torch.randn(B * T, C, generator=g).to(BF).double().requires_grad_(True) for _ in range(3))
+    seed, off = 0x5DEECE66D ^ (hd << 33), (5 << 40) + 77 * 1024
+
+    def heads(t):
+        return t.view(B, T, nh, hd).transpose(1, 2)
+
+    att = torch.softmax((heads(q) @ heads(k).transpose(-2, -1)) * (1.0 / math.sqrt(hd)), dim=-1)
+    if pdrop > 0:
+        att = att * _keep_mask(seed, off, (B, nh, T, T), pdrop, dtype=torch.float64)
+    o = (att @ heads(v)).transpose(1, 2).reshape(B * T, C)
+    do = torch.randn(B * T, C, generator=g).to(BF).double()
+    o.backward(do)
+    dev16 = lambda t: t.detach().to(BF).cuda()  # noqa: E731
+    qg, kg, vg, dog = dev16(q), dev16(k), dev16(v), dev16(do)
+    ws = ops.Workspace(dev, max(int(lib().attention_workspace_bytes(B, T, nh, hd, C)), 256 << 20))
+    kw = dict(drop_p=pdrop, seed=seed, seed_off=off) if pdrop > 0 else {}
+    og, lse = ops.attention_fwd_bf16(qg, kg, vg, B, T, nh, ws, *((pdrop, seed, off) if pdrop > 0 else ()))
+    bar = lambda a, b: (a.double().cpu() - b).abs().max().item() / b.abs().max().item()  # noqa: E731
+    assert bar(og, o.detach()) < 2e-2   # builder-declared bar of the bf16-stored kernels (tests/test_bgemm_gpu.py)
+    dq, dk, dv = ops.attention_bwd_bf16io(qg, kg, vg, og, dog, lse, B, T, nh, ws, **kw)
+    for got, want, name in ((dq, q.grad, "dq"), (dk, k.grad, "dk"), (dv, v.grad, "dv")):
+        assert bar(got, want) < 2e-2, (name, bar(got, want))
+    torch.cuda.synchronize()
+
+
+def _attention_case(dev, hd, pdrop, B, T):
     """B = 12, T = 962, 4 heads: forward, and both backward forms (dS / P hand-over = 5 products, and the recomputing
     form) against torch autograd on the materialised scores.  pdrop = 0.1 is what bench.py times (attn_pdrop of
     /root/reference/model2_seq.py:103-105): the keep mask of all B * nh * T * T probabilities is rebuilt on the CPU from
@@ -256,7 +305,7 @@ def test_attention_at_bench_batch(dev, hd, pdrop):
     a multiple of the row length, like a mid-forward site of the model."""
     from deepsense6g_tii_amd import ops
     from deepsense6g_tii_amd._lib import lib
-    B, T, nh = 12, 962, 4
+    nh = 4
     C = nh * hd
     torch.set_num_threads(_threads())
     g = torch.Generator().manual_seed(hd)

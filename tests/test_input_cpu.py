@@ -51,3 +51,32 @@ def test_soft_beam_target_closed_form():
     got = pkg_target(torch.tensor([0, 31, 63]))
     want = np.stack([dr.soft_beam_target(i)[0] for i in (0, 31, 63)]).astype(np.float32)
     assert np.allclose(got.numpy(), want, rtol=1e-6, atol=1e-12)
+
+
+GOLD_ITEM = os.path.join(os.path.dirname(__file__), "golden", "getitem_golden.npz")
+
+
+def getitem_cases():
+    g = np.load(GOLD_ITEM)
+    return g, [tuple(int(v) for v in g[k]) for k in sorted(g.files) if k.endswith("_meta")]
+
+
+def test_whole_sample_matches_reference_getitem_fixture():
+    """oracle/data_ref.py::getitem against the outputs of the reference's own CARLA_Data.__getitem__ run end to end on the same
+    synthetic files (tests/golden/make_golden_getitem.py): soft beam target, beam index and GPS in full, frames / radar maps /
+    BEV histograms by strided samples and sums - flip on and off, custom field of view, with and without the velocity map,
+    beams at both ends of the codebook."""
+    g, cases = getitem_cases()
+    assert len(cases) == 6 and {c[3] for c in cases} == {0, 1} and {c[2] for c in cases} >= {1, 64}
+    for seed, scen, beam1, flip, fov, vel in cases:
+        mine = dr.getitem(seed, scen, beam1, bool(flip), bool(fov), vel)
+        key = f"case{seed}"
+        assert np.array_equal(mine["beam"], g[key + "_beam"]) and int(mine["beamidx"]) == int(g[key + "_beamidx"])
+        assert np.array_equal(mine["gps"], g[key + "_gps"])
+        for t in range(5):
+            for name, arr in ((f"front{t}", mine["fronts"][t]), (f"radar{t}", mine["radars"][t]), (f"lidar{t}", mine["lidars"][t])):
+                flat = np.ascontiguousarray(arr).reshape(-1)
+                want = g[f"{key}_{name}_sample"]
+                assert flat.dtype == want.dtype and np.array_equal(flat[::997], want), (key, name)
+                assert float(flat.astype(np.float64).sum()) == float(g[f"{key}_{name}_sum"]), (key, name)
+        assert mine["radars"][0].shape == ((2 if vel else 1), 256, 256)

@@ -103,3 +103,46 @@ def test_model_accepts_packed_inputs(dev):
     model.train()
     loss, logits = model.train_step_loss(pk, None, None, None, pk.target)
     assert torch.isfinite(loss).all() and model.join[4].weight.grad is not None
+
+
+@pytest.mark.parametrize("flip", [False, True])
+def test_pipeline_matches_reference_getitem_fixture(dev, flip):
+    """DeviceInputPipeline on the decoded files of the fixture's samples (tests/golden/getitem_golden.npz: outputs of the
+    reference's own CARLA_Data.__getitem__) - the packed batch must reproduce them bit for bit after the casts of Engine.train
+    (train2_seq.py:111-116: fp32) and normalize_imagenet: soft target / beam index / GPS against the stored values, frames /
+    radar / BEV against the oracle sample that the CPU test pins to the fixture's samples and sums."""
+    from deepsense6g_tii_amd.data import DeviceInputPipeline
+    from oracle import data_ref as dr
+    from tests.test_input_cpu import getitem_cases
+    g, cases = getitem_cases()
+    fov = True      # one pipeline = one (flip, field-of-view) setting; the fixture's custom-FoV samples with both radar maps
+    cases = [c for c in cases if bool(c[3]) == flip and c[4] == 1 and c[5] == 1]
+    assert len(cases) >= 1
+    B, S = len(cases), 5
+    samples = [dr.make_getitem_files(c[0], c[1], c[2], fov) for c in cases]
+    base = [f"scenario{c[1]}/unit1/" for c in cases]
+    images = [np.stack([samples[b][0][base[b] + f"camera_data_aug/image_{t + 1}_1.jpg"] for b in range(B)]) for t in range(S)]
+    clouds = [[samples[b][0][base[b] + f"lidar_data/cloud_{t + 1}.ply"] for b in range(B)] for t in range(S)]
+    radars = [np.stack([np.stack([samples[b][0][base[b] + f"radar_data_ang/radar_{t + 1}.npy"],
+                                  samples[b][0][base[b] + f"radar_data_vel/radar_{t + 1}.npy"]]) for b in range(B)]) for t in range(S)]
+    gps = np.stack([samples[b][2] for b in range(B)])
+    beam = np.array([c[2] - 1 for c in cases])
+    pk = DeviceInputPipeline(dev, seq_len=S, custom_fov=fov, flip=flip).pack(images, clouds, radars, gps, beam, base)
+    torch.cuda.synchronize()
+    img = pk.images.cpu().numpy().reshape(B, S, 256, 256, 4)
+    lid = pk.lidars.cpu().numpy().reshape(B, S, 256, 256, 4)
+    rad = pk.radars.cpu().numpy().reshape(B, S, 256, 256, 4)
+    for b, c in enumerate(cases):
+        key = f"case{c[0]}"
+        assert np.array_equal(pk.target[b].cpu().numpy(), g[key + "_beam"].astype(np.float32))
+        assert int(pk.beamidx[b]) == int(g[key + "_beamidx"])
+        assert np.array_equal(pk.gps[b].cpu().numpy(), g[key + "_gps"].astype(np.float32))
+        want = dr.getitem(c[0], c[1], c[2], flip, fov, 1)
+        for t in range(S):
+            fr32 = torch.from_numpy(np.ascontiguousarray(want["fronts"][t])).to(torch.float32)[None]
+            norm = fr32.clone()
+            for ch, (m, sdev) in enumerate(((0.485, 0.229), (0.456, 0.224), (0.406, 0.225))):   # model2_seq.py:36-45
+                norm[:, ch] = ((fr32[:, ch] / 255.0) - m) / sdev
+            assert np.array_equal(img[b, t, :, :, :3], norm[0].numpy().transpose(1, 2, 0)), (b, t)
+            assert np.array_equal(rad[b, t, :, :, :2], want["radars"][t].transpose(1, 2, 0)), (b, t)
+            assert np.array_equal(lid[b, t, :, :, 0], want["lidars"][t][0].astype(np.float32)), (b, t)

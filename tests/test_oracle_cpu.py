@@ -187,3 +187,47 @@ def test_ema_matches_reference_run():
     for s in range(5):
         shadow = tr.ema_update(shadow, steps[s, :n_tracked], 0.999)
     assert torch.equal(shadow, torch.from_numpy(g["ema_shadow"]))
+
+
+# ---- the 30 -> 5 variant (seq_len 10 => 1922 tokens, GRU head): fixture made by the REFERENCE's own model2_seq_30to5.py
+# Encoder + TransFuser.forward (tests/golden/make_golden_30to5.py) ---------------------------------------------------------
+GOLD30 = os.path.join(os.path.dirname(__file__), "golden", "fusion30to5_golden.npz")
+
+
+def golden30_case():
+    """-> (RefConfig, state dict, inputs, target) of the fixture, rebuilt from its stored seeds"""
+    gold = np.load(GOLD30)
+    state_seed, input_seed, target_seed, batch, seq_len, n_layer, pred_len = (int(v) for v in gold["meta"])
+    cfg = fr.RefConfig(seq_len=seq_len, n_layer=n_layer, pred_len=pred_len, gru_head=True, embd_pdrop=0.0, attn_pdrop=0.0,
+                       resid_pdrop=0.0)
+    sd = fr.make_state(cfg, seed=state_seed)
+    imgs, lids, rads, gps, _, _ = fr.make_inputs(cfg, batch, seed=input_seed)
+    target = torch.rand(batch, pred_len, 64, generator=torch.Generator().manual_seed(target_seed)) * 0.5
+    return gold, cfg, sd, (imgs, lids, rads, gps), target
+
+
+def test_30to5_variant_matches_reference_fixture():
+    """oracle at seq_len 10 (pos_emb of 1922 tokens, model2_seq_30to5.py:188) + join + GRUCell / Linear head unrolled
+    pred_len = 5 times (:846-862) against the outputs of the reference's own classes: predictions, fused features, loss,
+    nine gradient probes from the head down to the camera stem."""
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    gold, cfg, sd, inputs, target = golden30_case()
+    assert cfg.n_tokens == 1922
+    sdo = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not fr.is_buffer(k)) else v.clone())
+           for k, v in sd.items()}
+    cap = {}
+    pred = fr.transfuser_forward(sdo, *inputs, cfg, fr.Ctx(training=True, capture=cap))
+    loss = tr.sigmoid_focal_loss(pred, target)
+    loss.backward()
+    assert tuple(pred.shape) == (2, 5, 64)
+    assert np.abs(pred.detach().numpy() - gold["pred_b2"]).max() < 2e-5
+    assert np.abs(cap["fused"].detach().numpy() - gold["fused_b2"]).max() < 2e-4
+    assert abs(float(loss) - float(gold["loss_b2"])) < 1e-6
+    probes = [k[len("grad:"):-len(":head")] for k in gold.files if k.startswith("grad:") and k.endswith(":head")]
+    assert len(probes) == 9
+    for name in probes:
+        g = sdo[name].grad.flatten()
+        scale = float(gold[f"grad:{name}:absmax"])
+        assert np.abs(g[:16].numpy() - gold[f"grad:{name}:head"]).max() < 2e-4 * scale + 1e-12, name
+        assert np.abs(g[::max(1, g.numel() // 64)][:64].numpy() - gold[f"grad:{name}:strided"]).max() < 2e-4 * scale + 1e-12, name
+        assert abs(float(g.norm()) - float(gold[f"grad:{name}:l2"])) < 1e-4 * float(gold[f"grad:{name}:l2"]), name
