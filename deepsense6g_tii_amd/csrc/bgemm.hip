@@ -33,6 +33,8 @@ int ds6g_internal_splitk_reduce(const float* ws, float* dw, long n4, float* dbia
 int ds6g_internal_bn_stats_finalize(const double* partial, int nblk, long M, int C, float eps, float momentum, float* mean,
                                     float* invstd, float* running_mean, float* running_var, hipStream_t st);
 
+GCLK_STORAGE(g_bgemm_clk, g_bgemm_wg, ds6g_bgemm_clocks_read)
+
 namespace {
 
 enum { B_FWD = 0, B_DGRAD = 1, B_WGRAD = 2 };
@@ -80,10 +82,18 @@ struct BgemmParams {
 __device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(unsigned long)(lds_void*)p; }
 
 // MODE / BM x BN tile / OUT16: bf16 output through LDS (else fp32, direct) / EPI: fused epilogue (bias, ReLU, mask,
-// dropout, residual, accumulate) instead of a plain store
+// dropout, residual, accumulate) instead of a plain store.
+// What bounds the loop (round 4, -DDS6G_GEMM_CLOCKS + tools/gemm_clocks.py): a k-tile step of the 128 x 128 tile takes 2 800 -
+// 3 000 cycles for 2 x 512 cycles of MFMA per SIMD (two workgroups per CU): DMA issue 800 - 1 000 (8 pieces per wave), fragment
+// reads + MFMAs 1 100 - 1 200, DMA wait 550, barrier 330.  A 256 x 128 tile with 8 waves and THREE stages (two k-tiles in flight,
+// counted vmcnt, raw s_barrier) was built and measured: 975 vs 964 TFLOP/s at 4096^3, 46.0 vs 43.6 us on the stage-4 fc1
+// forward - the wait stays ~800 cycles per step with twice the prefetch distance, i.e. the L1 / texture-address load path
+// (32 KB per step and workgroup = 24 B / cycle / CU at 964 TFLOP/s) bounds it, not latency; only a tile with fewer bytes per
+// FLOP (256 x 256) would move it, and M = 11 544 rows / N <= 2 048 give that tile 92 - 368 workgroups on 256 CUs.  Not kept.
 template <int MODE, int BM, int BN, int OUT16, int EPI>
 __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
     BgemmParams p = pin;
+    GCLK_DECL(g_bgemm_wg);
     if (EPI && p.drop_thr && p.salt) p.seed_off += *p.salt;
     if (MODE == B_DGRAD && pin.nclass > 1) {
         const int ph = blockIdx.y >> 1, pw = blockIdx.y & 1;
@@ -98,6 +108,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
         if (p.Kg == 0 && p.accumulate) return;  // no tap hits this class: its pixels keep their value
     }
     constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 MFMA tiles per wave (wave grid 2 x 2)
+    constexpr int WR = BM / 2;                         // rows of the output tile per wave
     constexpr bool A_T = (MODE == B_WGRAD);            // operand staged [k][cols], read transposed
     constexpr bool B_T = (MODE != B_FWD);
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -187,12 +198,16 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
             const int mm = a_ok[i] ? m : 0;
             a_c[i] = kimg_kel(pi);
             if (MODE == B_FWD) {
-                const int ow = mm % p.Wo, t = mm / p.Wo, oh = t % p.Ho, n = t / p.Ho;
+                int ow, t, oh, n;
+                fast_divmod(mm, p.Wo, t, ow);
+                fast_divmod(t, p.Ho, n, oh);
                 a_y[i] = oh * p.stride - p.pad;
                 a_x[i] = ow * p.stride - p.pad;
                 a_base[i] = (unsigned)n * (unsigned)(p.H * p.W * p.C);
             } else {
-                const int ww = mm % p.Ws, t = mm / p.Ws, hh = t % p.Hs, n = t / p.Hs;
+                int ww, t, hh, n;
+                fast_divmod(mm, p.Ws, t, ww);
+                fast_divmod(t, p.Hs, n, hh);
                 a_y[i] = p.h0 + hh * p.hstep + p.pad;
                 a_x[i] = p.w0 + ww * p.wstep + p.pad;
                 a_base[i] = (unsigned)n * (unsigned)(p.Ho * p.Wo * p.K);
@@ -302,7 +317,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
 
     // ---- fragment addresses (bytes inside an operand image) --------------------------------------------------------
     // K image: lane (row, half) reads logical chunk 2s + half of its row for k-step s: one ds_read_b128
-    const unsigned ka_row = (unsigned)((wm * (BM / 2) + l31) * 128), kb_row = (unsigned)((wn * (BN / 2) + l31) * 128);
+    const unsigned ka_row = (unsigned)((wm * WR + l31) * 128), kb_row = (unsigned)((wn * (BN / 2) + l31) * 128);
     const unsigned kswz = (unsigned)((l31 >> 1) & 7);
     // T image: lane 4q + pp of a 16-lane group addresses row 16s + 8 half + 4t + q, columns c0 + 16 (group & 1) + 4 pp .. + 3
     const int tq = (lane >> 2) & 3, tpp = lane & 3, tgrp = (lane >> 4) & 1;
@@ -335,9 +350,9 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
             for (int i = 0; i < TM; ++i) {
                 if (A_T) {
                     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)(lds_void*)(Ac + t_addr(A_RB, wm * (BM / 2) + i * 32, s, 0)));
+                        (__attribute__((address_space(3))) bf16x4*)(lds_void*)(Ac + t_addr(A_RB, wm * WR + i * 32, s, 0)));
                     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)(lds_void*)(Ac + t_addr(A_RB, wm * (BM / 2) + i * 32, s, 1)));
+                        (__attribute__((address_space(3))) bf16x4*)(lds_void*)(Ac + t_addr(A_RB, wm * WR + i * 32, s, 1)));
                     af[s][i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 } else {
                     af[s][i] = *reinterpret_cast<const bf16x8*>(Ac + ka_row + i * 32 * 128 + ((((unsigned)(2 * s + khalf)) ^ kswz) << 4));
@@ -366,15 +381,32 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
     };
 
     // two stages: the DMA of tile t+1 flies under the MFMAs of tile t; one wait + barrier per k-tile
+    // the epilogue's bias values, fetched BEFORE the k loop (their memory latency hides under it; loaded at their use they
+    // were most of an 11 000-cycle epilogue in a 40 000-cycle workgroup life, -DDS6G_GEMM_CLOCKS)
+    [[maybe_unused]] float bias_pre[TN];
+    if (EPI) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+            bias_pre[j] = (p.bias && col < p.Ng) ? p.bias[col] : 0.f;
+        }
+    }
+    GCLK(g_bgemm_clk, 0);   // set-up (walk state, fragment addresses, accumulator zeroing)
     if (nk > 0) issue_tiles(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    GCLK(g_bgemm_clk, 1);   // first tile: DMA issue + its full latency + barrier
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) issue_tiles((kt + 1) & 1);
+        GCLK(g_bgemm_clk, 2);   // DMA issue of the next k-tile
         compute(kt & 1);
         __builtin_amdgcn_sched_barrier(0);
+        GCLK(g_bgemm_clk, 3);   // fragment reads + MFMA chain
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GCLK(g_bgemm_clk, 4);   // wait for the next tile's DMA
         __syncthreads();
+        GCLK(g_bgemm_clk, 5);   // barrier
+        GCLK_COUNT(g_bgemm_clk, 15);
     }
 
     // ---- epilogue: D[row][col], col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -------------------------
@@ -394,12 +426,14 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
                 if (col >= p.Ng) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    const int row = m0 + wm * WR + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                     if (row >= p.Mg) continue;
                     const size_t o = out_row(row) * p.Ng + col;
                     outp[o] = p.accumulate ? outp[o] + acc[i][j][r] : acc[i][j][r];
                 }
             }
+        GCLK(g_bgemm_clk, 6);
+        GCLK_END(g_bgemm_clk, g_bgemm_wg);
         return;
     }
     if (!OUT16) {
@@ -414,9 +448,9 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + wn * (BN / 2) + j * 32 + l31;
-                const int row0 = m0 + wm * (BM / 2) + i * 32 + 4 * khalf;
+                const int row0 = m0 + wm * WR + i * 32 + 4 * khalf;
                 const bool cok = col < p.Ng;
-                const float bias = (EPI && p.bias && cok) ? p.bias[col] : 0.f;
+                const float bias = EPI ? bias_pre[j] : 0.f;
                 const unsigned base = cok ? (unsigned)row0 * rowbytes + (unsigned)col * 4u : OOB_OFF;
                 const unsigned e0 = (unsigned)row0 * (unsigned)p.Ng + (unsigned)col;
 #pragma unroll
@@ -436,6 +470,8 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
                 }
             }
         }
+        GCLK(g_bgemm_clk, 6);   // epilogue (stores issued)
+        GCLK_END(g_bgemm_clk, g_bgemm_wg);
         return;
     }
     // bf16 output: epilogue arithmetic in fp32 on the accumulators, one rounding, then through a wave-private LDS patch
@@ -443,7 +479,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
     // every wave: the staging buffers are free)
     {
         __bf16* outp = reinterpret_cast<__bf16*>(p.out);
-        constexpr int PR = BM / 2, PC = BN / 2;
+        constexpr int PR = WR, PC = BN / 2;
         __bf16* patch = reinterpret_cast<__bf16*>(lds) + wave * PR * PC;
         const bool stats = !EPI && MODE == B_FWD && p.bn_partial != nullptr;
         float cs[TN], cq[TN];
@@ -455,8 +491,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + wn * PC + j * 32 + l31;
                 const int row0 = m0 + wm * PR + i * 32 + 4 * khalf;
-                const bool cok = col < p.Ng;
-                const float bias = (EPI && p.bias && cok) ? p.bias[col] : 0.f;
+                const float bias = EPI ? bias_pre[j] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dr = (r & 3) + 8 * (r >> 2);
@@ -464,13 +499,8 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
                     if (EPI) {
                         v += bias;
                         if (p.relu == 1) v = fmaxf(v, 0.f);
-                        const size_t e = (size_t)(row0 + dr) * p.Ng + col;
-                        if (p.mask_src && cok && row0 + dr < p.Mg) {
-                            const float mv = p.mask16 ? (float)reinterpret_cast<const __bf16*>(p.mask_src)[e]
-                                                      : reinterpret_cast<const float*>(p.mask_src)[e];
-                            v = mv > 0.f ? v : 0.f;
-                        }
-                        if (p.drop_thr) v = ds6g_keep(p.seed, p.seed_off + (uint64_t)e, p.drop_thr) ? v * p.drop_scale : 0.f;
+                        if (p.drop_thr)
+                            v = ds6g_keep(p.seed, p.seed_off + (uint64_t)((size_t)(row0 + dr) * p.Ng + col), p.drop_thr) ? v * p.drop_scale : 0.f;
                     }
                     const __bf16 vb = (__bf16)v;
                     patch[(i * 32 + 4 * khalf + dr) * PC + j * 32 + l31] = vb;
@@ -511,6 +541,25 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
             const int grow = m0 + wm * PR + rl, gcol = n0 + wn * PC + pc * 8;
             if (grow < p.Mg && gcol < p.Ng) {
                 bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + rl * PC + pc * 8);
+                if (EPI && p.mask_src) {
+                    // ReLU mask of the forward activation ([Mg][Ng], the output's own shape): applied here, where a lane holds
+                    // 8 consecutive columns of one row - one 16-byte (bf16) or two 16-byte (fp32) loads instead of 8 scalar
+                    // ones per lane in accumulator order (the masked dgrad ran 54.8 us against 27.7 us for the plain one)
+                    const size_t e = (size_t)grow * p.Ng + gcol;
+                    if (p.mask16) {
+                        const bf16x8 mv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.mask_src) + e);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = (float)mv[q] > 0.f ? v[q] : (__bf16)0.f;
+                    } else {
+                        const float* mp = reinterpret_cast<const float*>(p.mask_src) + e;
+                        const f32x4 m0v = *reinterpret_cast<const f32x4*>(mp), m1v = *reinterpret_cast<const f32x4*>(mp + 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[q] = m0v[q] > 0.f ? v[q] : (__bf16)0.f;
+                            v[4 + q] = m1v[q] > 0.f ? v[4 + q] : (__bf16)0.f;
+                        }
+                    }
+                }
                 bf16x8* dst = reinterpret_cast<bf16x8*>(outp + out_row(grow) * p.Ng + gcol);
                 if (p.accumulate) {
                     const bf16x8 old = *dst;
@@ -521,6 +570,8 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
             }
         }
     }
+    GCLK(g_bgemm_clk, 6);
+    GCLK_END(g_bgemm_clk, g_bgemm_wg);
 }
 
 // ------------------------------------------------------------------------------------------------

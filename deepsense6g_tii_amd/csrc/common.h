@@ -32,6 +32,53 @@
         }                                                                                      \
     } while (0)
 
+// -DDS6G_GEMM_CLOCKS (tools/gemm_clocks.py builds its own library, never the product one): per-phase shader clocks of the
+// implicit-GEMM kernels.  Lane 0 of wave 0 of ONE workgroup (the middle one of the grid) adds the s_memtime cycles it spends
+// in each phase to CLK[phase]; every workgroup also records the 100 MHz real-time stamps of its entry and exit in
+// WG[linear id][0 / 1], which gives the dispatch ramp and the tail of a launch.
+#ifdef DS6G_GEMM_CLOCKS
+#define GCLK_STORAGE(CLK, WG, READ)                                                                                      \
+    __device__ unsigned long long CLK[16];                                                                               \
+    __device__ unsigned long long WG[16384][2];                                                                          \
+    extern "C" int READ(unsigned long long* clk16, unsigned long long* wg, int nwg, int reset) {                         \
+        if (hipMemcpyFromSymbol(clk16, HIP_SYMBOL(CLK), sizeof(unsigned long long) * 16) != hipSuccess) return -1;       \
+        if (wg && hipMemcpyFromSymbol(wg, HIP_SYMBOL(WG), sizeof(unsigned long long) * 2 * nwg) != hipSuccess) return -1; \
+        if (reset) {                                                                                                     \
+            unsigned long long z[16] = {};                                                                               \
+            if (hipMemcpyToSymbol(HIP_SYMBOL(CLK), z, sizeof(z)) != hipSuccess) return -1;                               \
+            void* wga_ = nullptr;                                                                                        \
+            if (hipGetSymbolAddress(&wga_, HIP_SYMBOL(WG)) != hipSuccess || hipMemset(wga_, 0, sizeof(WG)) != hipSuccess) return -1; \
+        }                                                                                                                \
+        return 0;                                                                                                        \
+    }
+#define GCLK_DECL(WG)                                                                                                    \
+    const int gclk_id_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                                 \
+    const bool gclk_on_ = gclk_id_ == (int)(gridDim.x * gridDim.y * gridDim.z) / 2 && threadIdx.x == 0;                  \
+    if (threadIdx.x == 0 && gclk_id_ < 16384) WG[gclk_id_][0] = __builtin_amdgcn_s_memrealtime();                        \
+    unsigned long long gclk_t_ = __builtin_readcyclecounter();                                                           \
+    const unsigned long long gclk_t0_ = gclk_t_;
+#define GCLK(CLK, ph)                                                                                                    \
+    do {                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        const unsigned long long n_ = __builtin_readcyclecounter();                                                      \
+        if (gclk_on_) CLK[ph] += n_ - gclk_t_;                                                                           \
+        gclk_t_ = n_;                                                                                                    \
+    } while (0)
+#define GCLK_COUNT(CLK, ph) do { if (gclk_on_) CLK[ph] += 1; } while (0)
+#define GCLK_END(CLK, WG)                                                                                                \
+    do {                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        if (gclk_on_) CLK[14] += __builtin_readcyclecounter() - gclk_t0_;                                                \
+        if (threadIdx.x == 0 && gclk_id_ < 16384) WG[gclk_id_][1] = __builtin_amdgcn_s_memrealtime();                    \
+    } while (0)
+#else
+#define GCLK_STORAGE(CLK, WG, READ)
+#define GCLK_DECL(WG)
+#define GCLK(CLK, ph)
+#define GCLK_COUNT(CLK, ph)
+#define GCLK_END(CLK, WG)
+#endif
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -267,6 +314,22 @@ __device__ __forceinline__ void dma16(const i32x4 srd, unsigned lds_byte_addr, u
         : "=&s"(keep)
         : "v"(voffset), "s"(lds_byte_addr), "s"(srd), "s"(soffset)
         : "memory");
+}
+
+// m / d and m % d for 0 <= m < 2^22 without the ~40-instruction integer division sequence: float quotient estimate
+// (v_rcp_f32 is good to 1 ulp, so the estimate is off by at most one) and one correction step.  The kernels' set-up code
+// turns tile rows into (image, row, column) with these (16 divisions per lane in the 128 x 128 bgemm tile: ~1 us of every
+// workgroup's life before its first load is issued, -DDS6G_GEMM_CLOCKS).  Falls back to the exact division above 2^22.
+__device__ __forceinline__ void fast_divmod(int m, int d, int& q, int& r) {
+    if ((unsigned)m >= (1u << 22)) {
+        q = m / d;
+        r = m - q * d;
+        return;
+    }
+    q = (int)((float)m * __builtin_amdgcn_rcpf((float)d));
+    r = m - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
 }
 
 __device__ __forceinline__ unsigned lds_addr(const float* p) {

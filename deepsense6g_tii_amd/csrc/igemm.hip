@@ -38,6 +38,8 @@ extern int g_wino_kb64;         // winograd.hip: 64-channel workgroups (timing e
 #define IGEMM_STAGES_W 2
 #endif
 
+GCLK_STORAGE(g_igemm_clk, g_igemm_wg, ds6g_igemm_clocks_read)
+
 namespace {
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
@@ -97,6 +99,7 @@ template <int MODE, int BM, int BN, int EPI, int BK, int BF, int FAST>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams pin) {
     IgemmParams p = pin;
     if (EPI && p.drop_thr && p.salt) p.seed_off += *p.salt;
+    GCLK_DECL(g_igemm_wg);
     if (MODE == MODE_DGRAD && pin.nclass > 1) {
         // strided dgrad: blockIdx.y = input-pixel parity class (ph, pw); class (ph, pw) only sees the taps
         // r = (ph + pad) mod 2 (+2, ...), s likewise - all four classes of a layer run as ONE launch
@@ -189,18 +192,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams pin) {
             a_r[i] = tap / nsx;
             a_s[i] = tap - a_r[i] * nsx;
             if (MODE == MODE_FWD) {
-                const int ow = mm % p.Wo;
-                const int t = mm / p.Wo;
-                const int oh = t % p.Ho;
-                const int n = t / p.Ho;
+                int ow, t, oh, n;
+                fast_divmod(mm, p.Wo, t, ow);
+                fast_divmod(t, p.Ho, n, oh);
                 a_y[i] = oh * p.stride - p.pad;
                 a_x[i] = ow * p.stride - p.pad;
                 a_base[i] = (unsigned)n * (unsigned)(p.H * p.W * p.C);
             } else {
-                const int ww = mm % p.Ws;
-                const int t = mm / p.Ws;
-                const int hh = t % p.Hs;
-                const int n = t / p.Hs;
+                int ww, t, hh, n;
+                fast_divmod(mm, p.Ws, t, ww);
+                fast_divmod(t, p.Hs, n, hh);
                 a_y[i] = p.h0 + hh * p.hstep + p.pad;
                 a_x[i] = p.w0 + ww * p.wstep + p.pad;
                 a_base[i] = (unsigned)n * (unsigned)(p.Ho * p.Wo * p.K);
@@ -479,9 +480,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams pin) {
             if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (A_LD + B_LD)) : "memory");
             else if (rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GCLK(g_igemm_clk, 4);   // wait for this tile's DMA
             if (!(p.dbg & 4)) __syncthreads();
+            GCLK(g_igemm_clk, 5);   // barrier
         }
         if (rem >= NS - 1 && !(p.dbg & 1)) issue_tiles(An, Bn);
+        GCLK(g_igemm_clk, 2);       // DMA issue
         if (MODE == MODE_WGRAD && do_csum) {
 #pragma unroll
             for (int k = 0; k < BK; ++k) csum += Ac[k * BM + tid];
@@ -589,14 +593,30 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams pin) {
         // the current buffers before the DMA after next overwrites them.  sched_barrier pins the wait BEHIND the
         // MFMA chain (an asm wait does not order register-only instructions) so the DMA flies under the MFMAs.
         __builtin_amdgcn_sched_barrier(0);
+        GCLK(g_igemm_clk, 3);       // fragment reads + MFMA chain
+        GCLK_COUNT(g_igemm_clk, 15);
         if (NS == 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GCLK(g_igemm_clk, 4);
             if (!(p.dbg & 4)) __syncthreads();
+            GCLK(g_igemm_clk, 5);
         }
     };
 
     float* const Ast[4] = {As0, As1, As2, As3};
     float* const Bst[4] = {Bs0, Bs1, Bs2, Bs3};
+    // the epilogue's bias values, fetched BEFORE the k loop: loaded where they are used, the (two) dependent global loads
+    // cost a full memory latency under load at the very end of every workgroup (measured with -DDS6G_GEMM_CLOCKS: epilogue
+    // of the 128 x 64 forward 19 700 cycles of a 274 000-cycle workgroup life)
+    [[maybe_unused]] float bias_pre[TN];
+    if (EPI) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+            bias_pre[j] = (p.bias && col < p.Ng) ? p.bias[col] : 0.f;
+        }
+    }
+    GCLK(g_igemm_clk, 0);           // set-up
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u)
         if (u < nk && !(p.dbg & 16)) issue_tiles(Ast[u], Bst[u]);
@@ -604,6 +624,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams pin) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    GCLK(g_igemm_clk, 1);           // first tile(s) issued (NS == 2: and landed)
     for (int kt0 = 0; kt0 < nk; kt0 += NS) {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
@@ -640,6 +661,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams pin) {
                 }
             }
         }
+        GCLK(g_igemm_clk, 6);   // epilogue (stores issued)
+        GCLK_END(g_igemm_clk, g_igemm_wg);
         return;
     }
     if (!(MODE == MODE_DGRAD && p.hstep != 1)) {
@@ -658,7 +681,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams pin) {
                 const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
                 const int row0 = m0 + wm * (BM / 2) + i * 32 + 4 * khalf;
                 const bool cok = col < p.Ng;
-                const float bias = (p.bias && cok) ? p.bias[col] : 0.f;
+                const float bias = bias_pre[j];
                 const unsigned base = cok ? (unsigned)row0 * rowbytes + (unsigned)col * 4u : OOB_OFF;
                 const unsigned e0 = (unsigned)row0 * (unsigned)p.Ng + (unsigned)col;  // element index (dropout counter)
 #pragma unroll
@@ -677,6 +700,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams pin) {
                 }
             }
         }
+        GCLK(g_igemm_clk, 6);   // epilogue (stores issued)
+        GCLK_END(g_igemm_clk, g_igemm_wg);
         return;
     }
     // strided dgrad: rows of the parity-class sub-grid scatter to full-resolution pixels
@@ -701,6 +726,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams pin) {
             }
         }
     }
+    GCLK(g_igemm_clk, 6);
+    GCLK_END(g_igemm_clk, g_igemm_wg);
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_s part[s*stride + i].  256 threads = 16 float4 columns x 16 split-lanes
