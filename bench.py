@@ -182,7 +182,7 @@ def roofline_from_records(agg, dtype, traffic):
 def pmc_traffic_table():
     """HBM bytes per launch by kernel name from the committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and WRITE_SIZE
     are collected in separate runs of this same command, so bench.py cannot measure them live; {} when absent."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if os.path.exists(path):
             return {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(path))["kernels"].items()}
@@ -214,6 +214,121 @@ class IgemmTimer:
             d[1] += fl[i]
             d[2] += ms[i]
         return agg
+
+
+PEAK_HBM_TBS = 8.0   # MI355X_MICROARCH.md: HBM3E ~8 TB/s spec (~6.3 achievable by a streaming kernel)
+
+
+def hbm_families(model, opt, batch, ema, reducer):
+    """The HBM-bound half of the roofline: one extra single-stream training step (outside the timed region) in which every call
+    of the BatchNorm / LayerNorm / AdamW entry points is bracketed by HIP events on its launch stream; per family: calls,
+    ms per step, ALGORITHMIC bytes (the tensors the operation must read and write once per pass, DESIGN.md section 3: BN
+    statistics 1 read; BN apply 1 read (+ residual) + 1 write; BN backward two passes over dy and x (+ the mask tensor) and
+    one write of dx (+ dres); LayerNorm forward 1 + 1, backward reads dy, x (+ add) and writes dx (+ its dropout copy);
+    AdamW 28 B per parameter, + 12 with the EMA shadow) and achieved TB/s = bytes / time.  A call = its reduction, finalize
+    and apply kernels together, so small layers read low (kernel-boundary latency), large ones approach the streaming rate."""
+    from deepsense6g_tii_amd._lib import lib
+    L = lib()
+    recs = []
+    saved = {}
+
+    def wrap(name, fam, nbytes):
+        orig = getattr(L, name)
+        saved[name] = orig
+
+        def call(*a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(*a)
+            e1.record()
+            recs.append((fam, float(nbytes(a)), e0, e1))
+        setattr(L, name, call)
+
+    n_ = lambda v: 1 if v else 0  # noqa: E731
+    for pre, eb in (("", 4), ("bf16_", 2)):   # fp32 storage, and the bf16-storage variants (other_modes)
+        wrap(pre + "bn_stats", "batchnorm statistics", lambda a, eb=eb: a[1] * a[2] * eb)
+        wrap(pre + "bn_apply", "batchnorm apply (+ReLU, +residual)", lambda a, eb=eb: (2 + n_(a[5])) * a[7] * a[8] * eb)
+        wrap(pre + "bn_bwd", "batchnorm backward (reduce + apply)",
+             lambda a, eb=eb: (2 * (2 + n_(a[1])) + 1 + n_(a[10])) * a[11] * a[12] * eb)
+    wrap("layernorm_fwd", "layernorm forward", lambda a: 2 * a[6] * a[7] * 4)
+    wrap("layernorm_bwd", "layernorm backward", lambda a: (3 + n_(a[5]) + n_(a[12])) * a[9] * a[10] * 4)
+    wrap("adamw_step_dev", "adamw (+ema)", lambda a: a[5] * (28 + (12 if a[4] else 0)))
+    ms_flag = model.multi_stream
+    model.multi_stream = False
+    try:
+        from deepsense6g_tii_amd.train import train_iteration
+        train_iteration(model, opt, batch, ema, reducer)
+        torch.cuda.synchronize()
+    finally:
+        model.multi_stream = ms_flag
+        for name, orig in saved.items():
+            setattr(L, name, orig)
+    fam = {}
+    for f, nb, e0, e1 in recs:
+        d = fam.setdefault(f, [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += nb
+        d[2] += e0.elapsed_time(e1)
+    return {f: dict(calls_per_step=c, ms_per_step=round(ms, 3), algorithmic_gb_per_step=round(nb / 1e9, 3),
+                    achieved_tb_s=round(nb / (ms * 1e-3) / 1e12, 2), frac_of_hbm_peak=round(nb / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 3))
+            for f, (c, nb, ms) in sorted(fam.items(), key=lambda kv: -kv[1][2]) if ms > 0}
+
+
+def eval_leg(model, batch, nbatch, steps=20):
+    """f2 in the driver line: eval-mode inference (BatchNorm folded into the conv weights, no dropout, no tape) on the timed
+    configuration's batch, samples/s (train2_seq.py:158-221 forward part)."""
+    was = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            for _ in range(3):
+                model(*batch[:4])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = model(*batch[:4])
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+        return dict(value=nbatch * steps / el, unit="samples/s", ms_per_batch=el / steps * 1e3, batch=nbatch, steps=steps,
+                    what="eval-mode forward, BatchNorm folded into the conv weights (ds6g_bn_fold), fp32, "
+                         "(B, 64) logits; f2 of SURVEY 8", finite=bool(torch.isfinite(out).all()))
+    finally:
+        model.train(was)
+
+
+def seq10_leg(dev, batch=4, steps=5):
+    """f4 in the driver line: one training configuration of the 30 -> 5 variant (/root/reference/model2_seq_30to5.py: seq_len
+    10 => 1922 tokens per sample, GRU beam-sequence head, pred_len 5, gradient clip 3.0 of train2_seq_30to5.py:120), bs=4,
+    exact fp32, dropout 0.1: ms per step and samples/s."""
+    from deepsense6g_tii_amd.model import GlobalConfig, TransFuser30to5
+    from deepsense6g_tii_amd.synthetic import make_batch
+    from deepsense6g_tii_amd.train import FusedAdamW, train_iteration
+    cfg = GlobalConfig(seq_len=10, pred_len=5)
+    torch.manual_seed(100)
+    model = TransFuser30to5(cfg, dev)
+    model.train()
+    opt = FusedAdamW(model, lr=1e-4, max_grad_norm=3.0)
+    fronts, lidars, radars, gps, target, _ = make_batch(batch, cfg.seq_len, cfg.n_views, cfg.add_velocity, seed=100, device=dev)
+    tgt = target[:, None, :].expand(batch, cfg.pred_len, 64).contiguous()
+    b = (fronts, lidars, radars, gps, tgt)
+    for _ in range(2):
+        train_iteration(model, opt, b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = train_iteration(model, opt, b)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = dict(value=batch * steps / el, unit="samples/s", ms_per_step=el / steps * 1e3, batch=batch, steps=steps, seq_len=10,
+               tokens=cfg_tokens(cfg), loss=float(loss),
+               what="TransFuser30to5 training step (seq_len 10, 1922 tokens, GRU head, pred_len 5, global-norm clip 3.0), fp32")
+    del model, opt
+    torch.cuda.empty_cache()
+    return out
+
+
+def cfg_tokens(cfg):
+    return (cfg.n_views + 2) * cfg.seq_len * cfg.vert_anchors * cfg.horz_anchors + 2
 
 
 def dba_leg(dev, steps=150, batch=12, pool=16, eval_batches=4, eval_every=50):
@@ -280,6 +395,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-modes", action="store_true",
                     help="skip the extra f32x3 / f32x6 / bf16 / bf16-image-only timings beside the exact-fp32 value")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the hbm_families / eval / seq10 legs")
     ap.add_argument("--no-dba", action="store_true", help="skip the held-out DBA leg (150 training steps on the synthetic learnable task)")
     ap.add_argument("--dba-steps", type=int, default=150)
     ap.add_argument("--dtype", choices=("f32", "bf16", "f32x3", "f32x6"), default="f32",
@@ -386,6 +502,19 @@ def main():
         table = pmc_traffic_table()
         roof = roofline_from_records(agg, args.dtype, lambda v: table.get(variant_name(v, args.dtype)))
 
+    # ---- the HBM-bound kernel families of the same step, the eval-mode forward (f2) and the seq_len-10 variant (f4):
+    # separate untimed legs of a few seconds each
+    hbm = ev = None
+    if rank == 0 and world == 1 and not args.no_extra_legs:
+        try:
+            hbm = hbm_families(model, opt, batch, ema, reducer)
+        except Exception as e:
+            hbm = {"error": repr(e)}
+        try:
+            ev = eval_leg(model, batch, args.batch)
+        except Exception as e:
+            ev = {"error": repr(e)}
+
     # ---- the other matrix-core modes next to the exact one (same model / timing protocol; reported beside `value`, never
     # as it): split-bf16 on the same batch, and the bf16 configuration BASELINE configs[1] names ----
     alt = None
@@ -458,6 +587,15 @@ def main():
         except Exception as e:
             dba = {"error": repr(e)}
 
+    seq10 = None
+    if rank == 0 and world == 1 and not args.no_extra_legs and args.dtype == "f32":
+        del model, opt
+        torch.cuda.empty_cache()
+        try:
+            seq10 = seq10_leg(dev)
+        except Exception as e:
+            seq10 = {"error": repr(e)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_batch, args.cpu_steps, 1, 2, args.cpu_small_steps, 3)
@@ -495,6 +633,9 @@ def main():
             "cpu_baseline": cpu,
             "other_modes": alt,
             "dba": dba,
+            "hbm_families": hbm,
+            "eval": ev,
+            "seq10": seq10,
         }
         if cpu:
             out["gpu_over_cpu"] = value / cpu["value"]
