@@ -133,6 +133,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 // dst[i] = bf16(src[i]) (RNE): the bf16 shadow of the parameter arena, refreshed once per training forward of the
 // bf16-storage path (fp32 master weights stay in the arena)
+// resident for `ticks` of the 100 MHz real-time counter (ds6g_debug_occupy_cus); touches its dynamic LDS so the allocation is real
+__global__ __launch_bounds__(256) void occupy_kernel(unsigned long long ticks) {
+    extern __shared__ unsigned char occ_lds[];
+    if (threadIdx.x == 0) occ_lds[0] = 1;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n4) {
     typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -328,6 +336,21 @@ int ds6g_cast_f32_bf16(const float* src, void* dst, long n, void* stream) {
     const long n4 = n / 4;
     const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n4);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+// Multi-GPU rehearsal on one GPU (tests/test_dp_gpu.py, tools/coresidency.py): `workgroups` workgroups of 256 threads, each
+// holding `lds_bytes` of LDS, stay resident for `microseconds` (100 MHz real-time counter; every wave leaves when the time is
+// up, so the grid always drains) - a stand-in for the channel workgroups a collective-communication kernel keeps on a few CUs
+// during the backward pass.  With lds_bytes > 32 KiB a persistent winograd_pc_kernel workgroup (128 KiB of LDS) cannot share
+// the CU.
+int ds6g_debug_occupy_cus(int workgroups, int lds_bytes, int microseconds, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(workgroups > 0 && workgroups <= 256 && lds_bytes >= 0 && lds_bytes <= 64 * 1024 && microseconds > 0 &&
+                   microseconds <= 2000000);
+    hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(256), (size_t)lds_bytes, (hipStream_t)stream,
+                       (unsigned long long)microseconds * 100ull);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }

@@ -136,3 +136,32 @@ def attach(model, optimizer, group=None, min_bucket_elems=8 << 20):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     model.set_dropout_seed(model._base_seed, rank)   # from the UNMIXED seed: attach() twice, or after a resume, mixes once
     return red
+
+
+def concurrent_side_stream(device, tries=8):
+    """A HIP stream whose kernels really run BESIDE those of the calling thread's current stream.  HIP multiplexes streams
+    onto a few hardware queues; two streams that share a queue execute in order, which would turn a co-residency rehearsal
+    (ds6g_debug_occupy_cus next to the training step) into a serial one.  Probed, not assumed: a 20 ms occupier goes to the
+    candidate stream, a tiny kernel to the current one - if the tiny kernel finishes while the occupier is still resident the
+    candidate is returned.  -> (stream, kept-alive list of the rejected candidates) or raises."""
+    import time
+
+    import torch
+
+    from ._lib import lib
+    cur = torch.cuda.current_stream(device)
+    probe = torch.zeros(4, device=device)
+    rejected = []
+    for _ in range(tries):
+        cand = torch.cuda.Stream(device)
+        torch.cuda.synchronize(device)
+        lib().debug_occupy_cus(4, 1024, 20_000, cand.cuda_stream)
+        t0 = time.perf_counter()
+        probe.add_(1.0)
+        cur.synchronize()
+        dt = time.perf_counter() - t0
+        torch.cuda.synchronize(device)
+        if dt < 0.010:
+            return cand, rejected
+        rejected.append(cand)
+    raise RuntimeError("no HIP stream found that runs concurrently with the current stream")

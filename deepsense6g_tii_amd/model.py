@@ -240,6 +240,8 @@ class TransFuser(nn.Module):
         self._use16 = False
         self._anchor = None
         self._arena = None
+        self._wfast = None     # parameter-pointer table of the walk in flight (see _run_forward)
+        self._wtable = None
         if self.device.type == "cuda":
             lib()  # fail loudly now if the HIP library is missing
             self._build_arena()
@@ -355,6 +357,8 @@ class TransFuser(nn.Module):
         # the hot path walks the parameter list several times per step (fresh / accumulate modes, arena check, zero_grad):
         # nn.Module.named_parameters() re-traverses the module tree each time (~3 ms of host per walk), the set is fixed
         self._plist = list(self.named_parameters())
+        a0 = self._arena.data_ptr()
+        self._wtable = {id(p): a0 + 4 * self._pslice[n][0] for n, p in self._plist}
 
     @property
     def _ws(self):
@@ -386,19 +390,19 @@ class TransFuser(nn.Module):
             self._side_streams = [torch.cuda.Stream(self.device) for _ in range(3)]
             for st in self._side_streams:
                 self._ws_side[st.cuda_stream] = ops.Workspace(self.device, 256 << 20)
-        cur = torch.cuda.current_stream()
+        cur = ops.current_stream_obj()
         for st in self._side_streams:
             st.wait_stream(cur)
         return self._side_streams
 
     def _join(self):
-        cur = torch.cuda.current_stream()
+        cur = ops.current_stream_obj()
         for st in self._side_streams:
             cur.wait_stream(st)
 
     def _trunk_ctx(self, streams, m):
         import contextlib
-        return torch.cuda.stream(streams[m]) if streams is not None else contextlib.nullcontext()
+        return ops.on_stream(streams[m]) if streams is not None else contextlib.nullcontext()
 
     def _apply(self, fn, recurse=True):
         # .to(same device) keeps the arena views; a real move would silently detach parameters from it
@@ -422,6 +426,9 @@ class TransFuser(nn.Module):
     # ---------------------------------------------------------------- pointers ------------------
     def _w(self, p):
         """device pointer of a parameter as the kernels expect it (conv: OHWI)."""
+        fast = self._wfast
+        if fast is not None:      # walk in flight with every parameter in the arena (checked once at its start)
+            return fast[id(p)]
         if p.dim() == 4 and not p.data.is_contiguous(memory_format=torch.channels_last):
             p.data = p.data.contiguous(memory_format=torch.channels_last)
         elif p.dim() != 4 and not p.data.is_contiguous():
@@ -475,6 +482,7 @@ class TransFuser(nn.Module):
             self.grad_ready_hook(k, lo, self._milestone_end[k])
 
     def _end_backward(self):
+        self._wfast = None
         owner = getattr(self.grad_ready_hook, "__self__", None)
         if owner is not None and hasattr(owner, "finish"):
             owner.finish()  # flush the tail bucket; the calling stream waits for every outstanding all-reduce
@@ -962,10 +970,15 @@ class TransFuser(nn.Module):
         clear, also when a launch raises): no later launch of this thread can pick up a stale salt"""
         if record and self.grad_ready_hook is not None:
             self._dp_check_fresh_grads()   # before the forward advances the salt, the BN running stats and _nbt
+        # parameter pointers of this walk: arena base + offset when every parameter still lives in the arena (one pass over
+        # the list instead of ~1250 Tensor.data round trips per step); re-pointed parameters (EMA shadow applied) -> live reads
+        self._wfast = self._wtable if (self._arena is not None and self.params_in_arena()) else None
         try:
             return self._run_forward_walk(images, lidars, radars, gps, record)
         finally:
             lib().set_dropout_salt(0)
+            if not record:
+                self._wfast = None   # a recorded forward keeps the table for its backward walk (cleared in _end_backward)
 
     def _run_forward_walk(self, images, lidars, radars, gps, record):
         L = lib()
@@ -1088,7 +1101,7 @@ class TransFuser(nn.Module):
         if not (self.multi_stream and self.overlap_wgrad):
             fn()
             return
-        cur = torch.cuda.current_stream()
+        cur = ops.current_stream_obj()
         if not self.overlap_wgrad_trunks and cur.cuda_stream in self._ws_side:  # a trunk stream
             fn()
             return
@@ -1098,7 +1111,7 @@ class TransFuser(nn.Module):
             self._wg_map[cur.cuda_stream] = side
             self._ws_side[side.cuda_stream] = ops.Workspace(self.device, 256 << 20)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
+        with ops.on_stream(side):
             fn()  # self._ws resolves to the companion stream's own scratch
         self._wg_used[side.cuda_stream] = side
         self._wg_keep.append(keep)  # dy / x must outlive the launch on the other stream
@@ -1106,7 +1119,7 @@ class TransFuser(nn.Module):
     def _wg_join(self):
         """the calling stream waits for every outstanding weight-gradient launch (gradients final after this)"""
         if self._wg_used:
-            cur = torch.cuda.current_stream()
+            cur = ops.current_stream_obj()
             for side in self._wg_used.values():
                 cur.wait_stream(side)
             self._wg_used = {}
@@ -1284,6 +1297,7 @@ class TransFuser(nn.Module):
             self._run_backward_walk(tape, dlogits)
         finally:
             lib().set_dropout_salt(0)
+            self._wfast = None
 
     def _run_backward_walk(self, tape, dlogits):
         L = lib()

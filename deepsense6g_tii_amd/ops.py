@@ -23,6 +23,40 @@ def _stream():
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
+_STREAM_OBJS = {}
+
+
+def current_stream_obj():
+    """torch.cuda.current_stream() without its ~8 us of device-index plumbing: Stream objects are cached by raw handle (the
+    walk switches streams ~400 times per step)"""
+    raw = _stream()
+    s = _STREAM_OBJS.get(raw)
+    if s is None:
+        s = torch.cuda.current_stream()
+        _STREAM_OBJS[s.cuda_stream] = s
+    return s
+
+
+class on_stream:
+    """`with torch.cuda.stream(s)` for the hot path: one C-level set-stream call each way, no Stream objects built"""
+    __slots__ = ("s", "prev")
+
+    def __init__(self, s):
+        self.s = s
+        _STREAM_OBJS.setdefault(s.cuda_stream, s)
+
+    def __enter__(self):
+        self.prev = current_stream_obj()
+        s = self.s
+        torch._C._cuda_setStream(stream_id=s.stream_id, device_index=s.device_index, device_type=s.device_type)
+        return s
+
+    def __exit__(self, *exc):
+        p = self.prev
+        torch._C._cuda_setStream(stream_id=p.stream_id, device_index=p.device_index, device_type=p.device_type)
+        return False
+
+
 def _chk(t, *shape):
     assert t.dtype == F32 and t.is_cuda and t.is_contiguous(), (t.dtype, t.device, t.stride())
     if shape:

@@ -37,6 +37,10 @@ int ds6g_profile_begin(int max_records);
 int ds6g_profile_end(int* variants, double* flops, float* ms, int cap);
 /* ablation switches for kernel timing experiments (results become wrong); 0 = normal operation */
 int ds6g_set_debug_flags(int flags);
+/* multi-GPU rehearsal on one GPU: keep `workgroups` (<= 256) workgroups of 256 threads with `lds_bytes` (<= 64 KiB) of LDS
+ * each resident for `microseconds` (<= 2 s; every wave leaves on time) on `stream` - a stand-in for the channel workgroups an
+ * RCCL all-reduce keeps on a few CUs while the backward pass runs (train2_seq.py:538 -> dist.py). */
+int ds6g_debug_occupy_cus(int workgroups, int lds_bytes, int microseconds, void* stream);
 /* matrix-core mode of the conv / linear / attention kernels (process-wide).  Everything else (BN, LN, softmax, loss,
  * AdamW, every accumulator) stays fp32 in every mode.  Returns DS6G_ERR_ARG for any other value.
  *   0 (default) "f32"   exact fp32 MFMA (v_mfma_f32_32x32x2_f32) - the parity path, 1e-3 bar against the reference.

@@ -137,3 +137,52 @@ def test_rccl_process_group_orders_buckets_after_their_producers(dev, tmp_path):
     assert r["nan_probe"] == [0] * len(issued), r["nan_probe"]
     assert all(r["ok_probe"]), r["ok_probe"]
     assert r["params_finite"]
+
+
+def test_persistent_winograd_kernel_next_to_resident_channel_workgroups(dev):
+    """Pre-validation of the 8-GPU run (no multi-GPU node): under data parallelism RCCL keeps a few channel workgroups resident
+    while the backward pass runs, and a winograd_pc_kernel workgroup needs a whole CU (512 threads x 256 VGPRs, 128 KiB of LDS) -
+    a full-size grid would run its last workgroups in a second round (2x that launch).  The default grid (the smallest one that
+    needs no more rounds than all CUs: 240 workgroups at the model's batch) leaves 16 CUs free: with 16 stand-in workgroups
+    (ds6g_debug_occupy_cus, 40 KiB of LDS each: no room for a persistent workgroup beside them) resident on a side stream, no
+    launch of the persistent kernel may take 1.6x its undisturbed time, and the results stay bit-identical."""
+    import ctypes
+    from deepsense6g_tii_amd import ops
+    from deepsense6g_tii_amd._lib import lib
+    L = lib()
+    N, H, W, C, K = 60, 32, 32, 128, 128
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, H, W, C, generator=g).to(dev)
+    w = (torch.randn(K, 3, 3, C, generator=g) * 0.05).to(dev)
+    u = ops.winograd_weights(w.data_ptr(), K, C, dev)
+    from deepsense6g_tii_amd.dist import concurrent_side_stream
+    side, _keep = concurrent_side_stream(dev)     # a stream that really overlaps the current one (probed)
+    CAP = 256
+
+    def timed(reps):
+        L.profile_begin(CAP)
+        ys = [ops.conv3x3_winograd(x, u, K) for _ in range(reps)]
+        var = (ctypes.c_int * CAP)(); fl = (ctypes.c_double * CAP)(); tm = (ctypes.c_float * CAP)()
+        k = L.profile_end(var, fl, tm, CAP)
+        t = sorted(tm[i] * 1e3 for i in range(k) if var[i] == 20002)
+        assert len(t) == reps, (len(t), [var[i] for i in range(k)])
+        return ys[-1], t
+
+    timed(3)
+    y0, t0 = timed(20)
+    L.debug_occupy_cus(16, 40 * 1024, 300_000, side.cuda_stream)      # resident for 0.3 s beside the launches below
+    import time
+    time.sleep(0.02)
+    t_host = time.perf_counter()
+    y1, t1 = timed(20)
+    torch.cuda.current_stream().synchronize()
+    assert time.perf_counter() - t_host < 0.15, "the launches waited for the occupier: not a co-residency measurement"
+    # the same with a FULL-size grid's worth of resident workgroups missing: 32 occupied CUs leave 224 < 240 -> a second round
+    L.debug_occupy_cus(16, 40 * 1024, 200_000, side.cuda_stream)
+    y2, t2 = timed(10)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(y0, y2)
+    print(f"with 32 resident workgroups: {t2[len(t2) // 2]:.1f} us median")
+    med0, med1, worst1 = t0[len(t0) // 2], t1[len(t1) // 2], t1[-1]
+    print(f"winograd_pc_kernel 60x32x32x128: {med0:.1f} us alone, {med1:.1f} us median / {worst1:.1f} us worst beside 16 resident workgroups")
+    assert med1 < 1.6 * med0 and worst1 < 2.0 * med0, (med0, med1, worst1)

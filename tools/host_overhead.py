@@ -21,3 +21,14 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"enqueue {1e3 * (t1 - t0) / n:.1f} ms/step, complete {1e3 * (t2 - t0) / n:.1f} ms/step, threads={torch.get_num_threads()}")
+# the enqueue wall time above includes back-pressure (hipLaunchKernel blocks when the launch queues are full, i.e. when the
+# host is FAR ahead).  What the host itself needs per step: enqueue ONE step into an idle GPU, several times
+cost = []
+for _ in range(6):
+    torch.cuda.synchronize()
+    a = time.perf_counter()
+    train_iteration(model, opt, batch)
+    cost.append(time.perf_counter() - a)
+    torch.cuda.synchronize()
+cost.sort()
+print(f"host cost of enqueueing one step into an idle GPU: median {1e3 * cost[len(cost) // 2]:.1f} ms, min {1e3 * cost[0]:.1f} ms")
