@@ -668,6 +668,19 @@ int ds6g_bn_bwd_maxpool_bf16in(const void* dpool, const uint8_t* idx, const floa
                                accumulate_param_grads, ws, ws_bytes, stream);
 }
 
+// bf16 stem (csrc/stem.hip): conv output x and its gradient dx are bf16 too
+int ds6g_bf16_stem_bn_bwd_maxpool(const void* dpool, const uint8_t* idx, const void* x, const float* mean,
+                                  const float* invstd, const float* gamma, const float* relu_beta, void* dx, float* dgamma,
+                                  float* dbeta, int N, int H, int W, int C, int accumulate_param_grads, void* ws,
+                                  size_t ws_bytes, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(dpool && idx && x && mean && invstd && gamma && relu_beta && dx && dgamma && dbeta && ws);
+    DS6G_CHECK_ARG(N > 0 && H > 0 && W > 0 && C % 4 == 0);
+    const PoolGrad pg{dpool, idx, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, 1};
+    return bn_bwd_run<__bf16, __bf16>(nullptr, pg, nullptr, (const __bf16*)x, mean, invstd, gamma, relu_beta, (__bf16*)dx,
+                                      dgamma, dbeta, nullptr, (long)N * H * W, C, accumulate_param_grads, ws, ws_bytes, stream);
+}
+
 int ds6g_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                        int M, int C, float eps, void* stream) {
     DS6G_ENTER();

@@ -18,7 +18,8 @@ __device__ __forceinline__ long tok_row(int f, int fps, int mod_off, int T, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ src, float* __restrict__ dst,
+template <typename TD>
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ src, TD* __restrict__ dst,
                                                          int B, int Cs, int HW, int Cd, int fps, int t,
                                                          int normalize) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -33,11 +34,11 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
         if (normalize) x = (x / 255.0f - mean[c]) / stdv[c];
         v[c] = x;
     }
-    float* o = dst + ((long)(b * fps + t) * HW + pix) * Cd;
+    TD* o = dst + ((long)(b * fps + t) * HW + pix) * Cd;
     if (Cd == 4) {
-        *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+        st4(o, f32x4{v[0], v[1], v[2], v[3]});
     } else {
-        for (int c = 0; c < Cd; ++c) o[c] = v[c];
+        for (int c = 0; c < Cd; ++c) o[c] = (TD)v[c];
     }
 }
 
@@ -61,8 +62,8 @@ __global__ void pad_channels_kernel(const float* __restrict__ src, float* __rest
 
 // ------------------------------------------------------------------------------------------------
 // bn_mean != NULL: the pooled tensor is relu(BN(x)), evaluated on the fly (the activation is never materialised)
-template <typename TY>
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, TY* __restrict__ y,
+template <typename TY, typename TX = float>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const TX* __restrict__ x, TY* __restrict__ y,
                                                           uint8_t* __restrict__ idx, int N, int H, int W, int C,
                                                           int Ho, int Wo, const float* __restrict__ bn_mean,
                                                           const float* __restrict__ bn_invstd,
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
         for (int s = 0; s < 3; ++s) {
             const int iw = ow * 2 - 1 + s;
             if (iw < 0 || iw >= W) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long)n * H + ih) * W + iw) * C + c4);
+            f32x4 v = ld4(x + (((long)n * H + ih) * W + iw) * C + c4);
             if (bn_mean) {
                 v = bn_affine(v, mu, is, gam, bet);
 #pragma unroll
@@ -431,8 +432,20 @@ int ds6g_pack_input(const float* src, float* dst, int B, int Cs, int H, int W, i
     DS6G_ENTER();
     DS6G_CHECK_ARG(src && dst && Cs >= 1 && Cs <= 4 && Cd >= Cs && Cd <= 4 && t >= 0 && t < frames_per_sample);
     DS6G_CHECK_ARG(!normalize_imagenet || Cs == 3);
-    hipLaunchKernelGGL(pack_input_kernel, dim3(grid1((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, src, dst, B,
+    hipLaunchKernelGGL(pack_input_kernel<float>, dim3(grid1((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, src, dst, B,
                        Cs, H * W, Cd, frames_per_sample, t, normalize_imagenet);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+// the same with a bf16 destination [B * frames][H][W][4] (the bf16 stem's input: csrc/stem.hip)
+int ds6g_pack_input_bf16(const float* src, void* dst, int B, int Cs, int H, int W, int frames_per_sample, int t,
+                         int normalize_imagenet, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(src && dst && Cs >= 1 && Cs <= 4 && t >= 0 && t < frames_per_sample);
+    DS6G_CHECK_ARG(!normalize_imagenet || Cs == 3);
+    hipLaunchKernelGGL(pack_input_kernel<__bf16>, dim3(grid1((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, src,
+                       (__bf16*)dst, B, Cs, H * W, 4, frames_per_sample, t, normalize_imagenet);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }
@@ -622,6 +635,18 @@ int ds6g_bn_relu_maxpool3x3s2_fwd_bf16out(const float* x, const float* mean, con
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipLaunchKernelGGL((maxpool_fwd_kernel<__bf16>), dim3(grid1((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
                        (hipStream_t)stream, x, (__bf16*)y, idx, N, H, W, C, Ho, Wo, mean, invstd, gamma, beta);
+    DS6G_LAUNCH_CHECK();
+    return DS6G_OK;
+}
+
+// bf16 stem (csrc/stem.hip): the conv output x is bf16 as well
+int ds6g_bf16_stem_bn_relu_maxpool_fwd(const void* x, const float* mean, const float* invstd, const float* gamma,
+                                       const float* beta, void* y, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+    DS6G_ENTER();
+    DS6G_CHECK_ARG(x && mean && invstd && gamma && beta && y && idx && C % 4 == 0 && N > 0 && H > 0 && W > 0);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL((maxpool_fwd_kernel<__bf16, __bf16>), dim3(grid1((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, idx, N, H, W, C, Ho, Wo, mean, invstd, gamma, beta);
     DS6G_LAUNCH_CHECK();
     return DS6G_OK;
 }

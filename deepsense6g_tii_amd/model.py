@@ -236,6 +236,7 @@ class TransFuser(nn.Module):
         # refreshed once per forward; csrc/bgemm.hip) instead of fp32 tiles rounded on the way into the MFMA.  fp32 stay: the
         # master weights, the residual stream, LayerNorm / softmax statistics, every accumulator, loss, optimizer.
         self.bf16_storage = True
+        self.bf16_stems = os.environ.get("DS6G_BF16_STEMS", "1") != "0"   # 7x7 stems on bf16 storage too (csrc/stem.hip)
         self._arena16 = None
         self._use16 = False
         self._anchor = None
@@ -636,6 +637,26 @@ class TransFuser(nn.Module):
     def _stem_fwd(self, trunk, cin, normalize, frames, train):
         L = lib()
         st = ops._stream()
+        if (self._use16 and self.bf16_stems and not self._fold_now and not torch.is_tensor(frames)
+                and ops.bf16_stem_ok(*frames[0].shape[2:])):
+            # bf16 configuration: the stem too on bf16 storage (csrc/stem.hip) - packed input, conv output and its gradient
+            # are bf16; the conv's epilogue delivers the BatchNorm statistics
+            B, S = frames[0].shape[0], len(frames)
+            H, W = frames[0].shape[2:]
+            x16 = torch.empty((B * S, H, W, 4), dtype=torch.bfloat16, device=self.device)
+            for t, f in enumerate(frames):
+                assert f.shape == (B, cin, H, W), (f.shape, (B, cin, H, W))
+                L.pack_input_bf16(f.data_ptr(), x16.data_ptr(), B, cin, H, W, S, t, int(normalize), st)
+            bn = trunk.bn1
+            stats = torch.empty(2, 64, dtype=F32, device=self.device)
+            if train:
+                c1 = ops.bf16_stem_fwd(x16, self._w(trunk.conv1.weight), cin, self._ws, (stats[0], stats[1]),
+                                       bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.eps, bn.momentum)
+            else:
+                c1 = ops.bf16_stem_fwd(x16, self._w(trunk.conv1.weight), cin, self._ws)
+                ops.bn_eval_prepare(bn.running_mean.data_ptr(), bn.running_var.data_ptr(), 64, stats[0], stats[1], bn.eps)
+            p1, idx = ops.bf16_stem_bn_relu_maxpool(c1, stats[0], stats[1], self._w(bn.weight), self._w(bn.bias))
+            return p1, (x16, c1, None, (stats[0], stats[1]), idx, cin)
         if torch.is_tensor(frames):  # data.PackedInputs: already NHWC x4, normalised
             x = frames
             assert x.dim() == 4 and x.shape[3] == 4 and x.dtype == F32 and x.is_contiguous() and x.device == self.device
@@ -1281,6 +1302,12 @@ class TransFuser(nn.Module):
         bn = trunk.bn1
         gw_bn, a_bn = self._g(bn.weight)
         gb_bn, _ = self._g(bn.bias)
+        if c1.dtype == torch.bfloat16:   # the bf16 stem (csrc/stem.hip)
+            dc1 = ops.bf16_stem_bn_bwd_maxpool(dpool, idx, c1, st1[0], st1[1], self._w(bn.weight), self._w(bn.bias), gw_bn,
+                                               gb_bn, self._ws, accumulate=bool(a_bn))
+            gw, aw = self._g(trunk.conv1.weight)
+            self._wg_launch(lambda: ops.bf16_stem_wgrad(x, dc1, gw, cin, self._ws, accumulate=bool(aw)), (x, dc1))
+            return
         bwd_pool = ops.bn_bwd_maxpool_bf16in if dpool.dtype == torch.bfloat16 else ops.bn_bwd_maxpool
         dc1 = bwd_pool(dpool, idx, c1, st1[0], st1[1], self._w(bn.weight), self._w(bn.bias), gw_bn, gb_bn,
                        self._ws, accumulate=bool(a_bn))

@@ -601,6 +601,52 @@ def bn_bwd_maxpool_bf16in(dpool, idx, x, mean, invstd, gamma_ptr, beta_ptr, dgam
     return dx
 
 
+# ---- the 7x7 / 2 stem convolutions of the bf16 configuration (csrc/stem.hip) -------------------------------------------
+def bf16_stem_ok(H, W):
+    return H % 16 == 0 and W % 32 == 0
+
+
+def bf16_stem_fwd(x16, w_ohwi_ptr, cin, ws: Workspace, stats=None, rm_ptr=0, rv_ptr=0, eps=1e-5, momentum=0.1):
+    """y = conv7x7/2(x) for x [N, H, W, 4] bf16 and the fp32 master filter [64, 7, 7, cin]; stats = (mean, invstd) fp32 [64]
+    tensors: also the train-mode BatchNorm statistics of y (running statistics updated in place)"""
+    N, H, W, C4 = x16.shape
+    _chk16(x16)
+    assert C4 == 4 and bf16_stem_ok(H, W) and ws.nbytes >= int(lib().bf16_stem_workspace_bytes())
+    y = torch.empty((N, H // 2, W // 2, 64), dtype=BF16, device=x16.device)
+    mean, invstd = stats if stats is not None else (None, None)
+    lib().bf16_stem_fwd(_p(x16), w_ohwi_ptr, cin, _p(y), N, H, W, eps, momentum, _p(mean), _p(invstd), rm_ptr, rv_ptr, ws.ptr,
+                        ws.nbytes, _stream())
+    return y
+
+
+def bf16_stem_wgrad(x16, dy16, dw_ptr, cin, ws: Workspace, accumulate=False):
+    N, H, W, C4 = x16.shape
+    _chk16(x16)
+    _chk16(dy16, N, H // 2, W // 2, 64)
+    assert C4 == 4 and bf16_stem_ok(H, W) and ws.nbytes >= int(lib().bf16_stem_workspace_bytes())
+    lib().bf16_stem_wgrad(_p(x16), _p(dy16), dw_ptr, cin, N, H, W, int(accumulate), ws.ptr, ws.nbytes, _stream())
+
+
+def bf16_stem_bn_relu_maxpool(x16, mean, invstd, gamma_ptr, beta_ptr):
+    N, H, W, C = x16.shape
+    _chk16(x16)
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((N, Ho, Wo, C), dtype=BF16, device=x16.device)
+    idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x16.device)
+    lib().bf16_stem_bn_relu_maxpool_fwd(_p(x16), _p(mean), _p(invstd), gamma_ptr, beta_ptr, _p(y), _p(idx), N, H, W, C, _stream())
+    return y, idx
+
+
+def bf16_stem_bn_bwd_maxpool(dpool, idx, x16, mean, invstd, gamma_ptr, beta_ptr, dgamma_ptr, dbeta_ptr, ws: Workspace, accumulate=False):
+    N, H, W, C = x16.shape
+    _chk16(x16)
+    _chk16(dpool, N, (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1, C)
+    dx = torch.empty_like(x16)
+    lib().bf16_stem_bn_bwd_maxpool(_p(dpool), _p(idx), _p(x16), _p(mean), _p(invstd), gamma_ptr, beta_ptr, _p(dx), dgamma_ptr,
+                                   dbeta_ptr, N, H, W, C, int(accumulate), ws.ptr, ws.nbytes, _stream())
+    return dx
+
+
 def _rows16(t, M, C):
     assert t.dtype == BF16 and t.is_cuda and tuple(t.shape) == (M, C) and t.stride(1) == 1 and t.stride(0) % 8 == 0, \
         (t.dtype, tuple(t.shape), t.stride())

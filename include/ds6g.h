@@ -150,6 +150,24 @@ int ds6g_bf16_linear_dgrad(const void* dy, const void* w, void* dx, int out16, i
 int ds6g_bf16_linear_wgrad(const void* x, const void* dy, float* dw, float* dbias, int M, int N, int K, int accumulate,
                            float* ws, size_t ws_bytes, void* stream);
 
+/* ---- stem.hip : the 7x7 / stride 2 / pad 3 stem convs (torchvision ResNet conv1 via model2_seq.py:495,500,505) of the
+ * bf16 configuration.  x [N][H][W][4] bf16 (ds6g_pack_input_bf16; channels >= cin zero), w: the fp32 master filter
+ * [64][7][7][cin] (OHWI), y / dy [N][H/2][W/2][64] bf16; H % 16 == 0, W % 32 == 0.  The forward also delivers the train-mode
+ * BatchNorm statistics of y (mean == NULL: convolution only); ws >= ds6g_bf16_stem_workspace_bytes().  The BN -> ReLU ->
+ * MaxPool pass over the bf16 conv output and its backward: ds6g_bf16_stem_bn_relu_maxpool_fwd / ds6g_bf16_stem_bn_bwd_maxpool. */
+size_t ds6g_bf16_stem_workspace_bytes(void);
+int ds6g_bf16_stem_fwd(const void* x, const float* w, int cin, void* y, int N, int H, int W, float eps, float momentum,
+                       float* mean, float* invstd, float* running_mean, float* running_var, void* ws, size_t ws_bytes,
+                       void* stream);
+int ds6g_bf16_stem_wgrad(const void* x, const void* dy, float* dw, int cin, int N, int H, int W, int accumulate, void* ws,
+                         size_t ws_bytes, void* stream);
+int ds6g_bf16_stem_bn_relu_maxpool_fwd(const void* x, const float* mean, const float* invstd, const float* gamma,
+                                       const float* beta, void* y, uint8_t* idx, int N, int H, int W, int C, void* stream);
+int ds6g_bf16_stem_bn_bwd_maxpool(const void* dpool, const uint8_t* idx, const void* x, const float* mean,
+                                  const float* invstd, const float* gamma, const float* relu_beta, void* dx, float* dgamma,
+                                  float* dbeta, int N, int H, int W, int C, int accumulate_param_grads, void* ws,
+                                  size_t ws_bytes, void* stream);
+
 /* ---- norm.hip ----------------------------------------------------------------------------------
  * BatchNorm2d in train mode (+ReLU, +residual add of BasicBlock): torchvision BasicBlock via
  * model2_seq.py:496-497,501-502,506-507 and the layer calls above; eval mode uses running stats. */
@@ -279,6 +297,8 @@ int ds6g_gru_head_bwd(const float* dpred, const float* h0, const float* saved, c
 /* normalize_imagenet + stack + NCHW->NHWC: model2_seq.py:36-45,481-482,491-493 */
 int ds6g_pack_input(const float* src, float* dst, int B, int Cs, int H, int W, int Cd, int frames_per_sample, int t,
                     int normalize_imagenet, void* stream);
+int ds6g_pack_input_bf16(const float* src, void* dst, int B, int Cs, int H, int W, int frames_per_sample, int t,
+                         int normalize_imagenet, void* stream);
 int ds6g_pad_channels(const float* src, float* dst, long rows, int cin, int cout, int unpad, int accumulate,
                       void* stream);
 /* MaxPool2d(3,2,1) of the stems: model2_seq.py:498,503,508 */

@@ -174,6 +174,58 @@ def test_bf16_conv_with_fused_batchnorm_statistics(dev, case):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("N,H,W,cin", [(3, 16, 32, 3), (2, 32, 64, 1), (5, 48, 32, 2), (2, 256, 256, 3), (7, 64, 96, 2)])
+def test_bf16_stem_conv_fwd_bn_statistics_and_wgrad(dev, N, H, W, cin):
+    """csrc/stem.hip (the 7x7 / 2 / pad 3 stems on bf16 storage) against torch in fp64 on the same bf16-rounded values: the conv
+    output (one rounding to bf16), the BatchNorm statistics of the stored output, the weight gradient (fp32, accumulation order
+    only) incl. the accumulate form, for every stem channel count; image borders, several tiles per workgroup and the 256 x 256
+    frames of the model."""
+    from deepsense6g_tii_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + H + cin)
+    x = r16(torch.randn(N, cin, H, W, generator=g)).double()
+    w = (torch.randn(64, cin, 7, 7, generator=g) / math.sqrt(49 * cin)).float()
+    w16 = r16(w).double().requires_grad_(True)             # the kernel rounds the fp32 master filter to bf16
+    y = F.conv2d(x, w16, None, 2, 3)
+    dy = r16(torch.randn(y.shape, generator=g)).double()
+    y.backward(dy)
+    x4 = torch.zeros(N, H, W, 4, dtype=BF)
+    x4[..., :cin] = x.permute(0, 2, 3, 1).to(BF)
+    xg = x4.cuda()
+    wg = w.permute(0, 2, 3, 1).contiguous().cuda()          # OHWI fp32
+    ws = ops.Workspace(dev, 64 << 20)
+    ws.buf.fill_(0xFF)
+    stats = torch.full((2, 64), float("nan"), device=dev)
+    rm, rv = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+    yg = ops.bf16_stem_fwd(xg, wg.data_ptr(), cin, ws, (stats[0], stats[1]), rm.data_ptr(), rv.data_ptr())
+    close16(yg.cpu().permute(0, 3, 1, 2), y.detach())
+    y2 = ops.bf16_stem_fwd(xg, wg.data_ptr(), cin, ws)      # convolution only (eval mode)
+    assert torch.equal(yg, y2)
+    yd = yg.double().cpu().reshape(-1, 64)
+    close32(stats[0], yd.mean(0), 1e-5)
+    close32(stats[1], 1.0 / torch.sqrt(yd.var(0, unbiased=False) + 1e-5), 1e-5)
+    close32(rv, 0.9 + 0.1 * yd.var(0, unbiased=True), 1e-5)
+    dyg = dy.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+    dw = torch.full((64, 7, 7, cin), float("nan"), device=dev)
+    ops.bf16_stem_wgrad(xg, dyg, dw.data_ptr(), cin, ws)
+    want = w16.grad.permute(0, 2, 3, 1)
+    close32(dw, want, 3e-5)
+    ops.bf16_stem_wgrad(xg, dyg, dw.data_ptr(), cin, ws, accumulate=True)
+    close32(dw, 2 * want, 3e-5)
+    # BN -> ReLU -> MaxPool over the bf16 conv output and its backward against the fp32-input forms on the same values
+    gam, bet = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
+    p16, idx16 = ops.bf16_stem_bn_relu_maxpool(yg, stats[0], stats[1], gam.data_ptr(), bet.data_ptr())
+    p32, idx32 = ops.bn_relu_maxpool_bf16out(yg.float(), stats[0], stats[1], gam.data_ptr(), bet.data_ptr())
+    assert torch.equal(p16, p32) and torch.equal(idx16, idx32)
+    dpool = r16(torch.randn(p16.shape, generator=g)).cuda()
+    dg16, db16, dg32, db32 = (torch.empty(64, device=dev) for _ in range(4))
+    dx16 = ops.bf16_stem_bn_bwd_maxpool(dpool, idx16, yg, stats[0], stats[1], gam.data_ptr(), bet.data_ptr(), dg16.data_ptr(), db16.data_ptr(), ws)
+    dx32 = ops.bn_bwd_maxpool_bf16in(dpool, idx16, yg.float(), stats[0], stats[1], gam.data_ptr(), bet.data_ptr(), dg32.data_ptr(), db32.data_ptr(), ws)
+    close32(dg16, dg32, 1e-6)
+    close32(db16, db32, 1e-6)
+    close16(dx16.cpu(), dx32.double().cpu())
+    torch.cuda.synchronize()
+
+
 def test_bf16_entry_points_reject_unsupported_shapes(dev):
     from deepsense6g_tii_amd import ops
     from deepsense6g_tii_amd._lib import Ds6gError
