@@ -1198,6 +1198,7 @@ int launch_hd_st(const AttnParams& p, int hd, dim3 grid, hipStream_t st) {
         }                                                                                                     \
         if constexpr (KIND == 4 && HDV >= 128) hipLaunchKernelGGL((attn_bwd_dv2_kernel<HDV, 4>), grid, dim3(256), 0, st, p); \
         if constexpr (KIND == 5) hipLaunchKernelGGL((attn_bwd_dq2_kernel<HDV, 4>), grid, dim3(256), 0, st, p); \
+        if constexpr (KIND == 6 && HDV >= 128) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDV, 0, 4, 1>), grid, dim3(256), 0, st, p); \
         break;
     switch (hd) {
         ATTN_CASE16(16)
@@ -1216,7 +1217,7 @@ int launch_hd_st(const AttnParams& p, int hd, dim3 grid, hipStream_t st) {
 template <int KIND>
 int launch_hd(const AttnParams& p, int hd, dim3 grid, hipStream_t st) {
     if (p.in16) {
-        if constexpr (KIND == 0 || KIND == 3 || KIND == 4 || KIND == 5) return launch_hd_st<KIND>(p, hd, grid, st);
+        if constexpr (KIND == 0 || KIND == 3 || KIND == 4 || KIND == 5 || KIND == 6) return launch_hd_st<KIND>(p, hd, grid, st);
         else return DS6G_ERR_ARG;
     }
     if (g_ds6g_bf16 == 3) return launch_hd_bf<KIND, 3>(p, hd, grid, st);
@@ -1348,8 +1349,11 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, in
         };
         // hd = 128, exact fp32: dK and dV in ONE kernel (one wave per SIMD, 512 registers, 37 of them spilled) instead of the
         // dK kernel + dropped-P tiles through HBM (201 MB per layer) + attn_bwd_dv2_kernel: measured 690 -> 669 us per
-        // backward at B = 12 (ds6g_set_debug_flags 0x04000000 restores the two-kernel form; the bf16 modes keep it)
-        const bool fused128 = hd >= 128 && g_ds6g_attn_fused128 && !g_ds6g_bf16 && !in16;
+        // backward at B = 12 (ds6g_set_debug_flags 0x04000000 restores the two-kernel form; the operand-rounding bf16 modes keep
+        // it).  bf16-STORED tiles (round 4): K / V fragments are packed bf16, the fused kernel needs 484 registers and no spill -
+        // bf16 step 431 -> 439 samples/s (DS6G_ATTN_FUSED128_BF16=0: the two-kernel form)
+        static const int fused16 = [] { const char* e = getenv("DS6G_ATTN_FUSED128_BF16"); return e ? atoi(e) : 1; }();
+        const bool fused128 = hd >= 128 && g_ds6g_attn_fused128 && (in16 ? fused16 != 0 : !g_ds6g_bf16);
         const bool two_pass = hd >= 128 && !fused128;
         plan(hd >= 128 ? 1 : (hd >= 64 ? 2 : 3), two_pass ? 1 : 2);
         p.dk = p.splits == 1 ? dk : wsf;
