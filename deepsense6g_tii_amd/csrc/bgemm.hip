@@ -90,6 +90,11 @@ __device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(u
 // forward - the wait stays ~800 cycles per step with twice the prefetch distance, i.e. the L1 / texture-address load path
 // (32 KB per step and workgroup = 24 B / cycle / CU at 964 TFLOP/s) bounds it, not latency; only a tile with fewer bytes per
 // FLOP (256 x 256) would move it, and M = 11 544 rows / N <= 2 048 give that tile 92 - 368 workgroups on 256 CUs.  Not kept.
+// Also built, parity-tested and measured: a producer / consumer form of the 128 x 128 tile (512 threads: waves 4 - 7 only issue
+// the DMA two tiles ahead, waves 0 - 3 only multiply, three stages, one workgroup per CU) - 812 vs 1 004 TFLOP/s at 4096^3,
+// slower on every model shape but the 240-workgroup 16x16x256 layers (28.3 -> 23.7 us): the step is then paced by the producer
+// wave's own issue chain (8 pieces = 800 - 1 000 cycles, i.e. ~27 cycles per KiB and CU through the texture-address unit),
+// which is the same load-path limit seen from the other side (profiles/r04_bgemm_classic_vs_producer_consumer.txt).  Not kept.
 template <int MODE, int BM, int BN, int OUT16, int EPI>
 __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
     BgemmParams p = pin;
