@@ -904,10 +904,24 @@ __global__ __launch_bounds__(256, (HD <= 16 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
         ATTN_CLK(3);   // elementwise (exp, dropout hash, dS)
         if (HAND) {  // tile image: [reg / 4][lane][reg % 4] - four 1-KiB stores per wave and tensor
             const size_t tile = ((((size_t)(b * p.nh + h) * p.nkg + qt) * p.nkg) + (bx_ * 4 + wave)) * 1024 + lane * 4;
+            if (BF == 4) {
+                // bf16-stored path: attn_bwd_dq2_kernel rounds dS to bf16 on its way into the MFMA anyway, so the tile is handed
+                // over AS bf16 - [reg / 8][lane][reg % 8], two 1-KiB stores, half the HBM bytes in both kernels (dQ from dS
+                // was HBM-bound on these tiles: 201 MB per layer at bs = 12), bit-identical dQ
+                bf16x8* ds16 = reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.hs) + (tile - lane * 4) + lane * 8);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    bf16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = key_ok ? (__bf16)dp[8 * g + e] : (__bf16)0.f;
+                    ds16[g * 64] = v;
+                }
+            } else {
             f32x4* ds_out = reinterpret_cast<f32x4*>(p.hs + tile);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 ds_out[g * 64] = key_ok ? f32x4{dp[4 * g], dp[4 * g + 1], dp[4 * g + 2], dp[4 * g + 3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             if (PART == 2) {
                 f32x4* p_out = reinterpret_cast<f32x4*>(p.hp + tile);
 #pragma unroll
@@ -925,7 +939,7 @@ __global__ __launch_bounds__(256, (HD <= 16 ? 3 : (HD <= 64 ? 2 : (PART == 1 ? 2
         ATTN_CLK(6);   // dK product
         // the next tile's DMA is older than this step's hand-over stores and vmcnt retires in order: wait for the DMA
         // only, the 4 (8) stores drain under the next step
-        if (HAND) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PART == 2 ? 8 : 4) : "memory");
+        if (HAND) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((BF == 4 ? 2 : 4) + (PART == 2 ? 4 : 0)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ATTN_CLK(7);   // wait for the next tile's DMA
         __syncthreads();
@@ -1015,6 +1029,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const AttnParams p
     const bool have = qt < ntiles;  // wave-uniform: query tiles beyond T were never written
     float f[16], fn[16];
     auto fetch = [&](float* dst, int kt) {
+        if (BF == 4) {   // bf16 tiles [reg / 8][lane][reg % 8] (see attn_bwd_dkv_kernel)
+            const __bf16* t16 = reinterpret_cast<const __bf16*>(p.hs) + ((((size_t)(b * p.nh + h) * p.nkg + qt) * p.nkg) + kt) * 1024 + lane * 8;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                bf16x8 v;
+                if (have) v = *reinterpret_cast<const bf16x8*>(t16 + g * 512);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[8 * g + e] = have ? (float)v[e] : 0.f;
+            }
+            return;
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 v = have ? *reinterpret_cast<const f32x4*>(tiles + (size_t)kt * 1024 + g * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
