@@ -1284,7 +1284,7 @@ static int attention_fwd_impl(const float* q, const float* k, const float* v, in
     p.bytes = (unsigned)(slab * esz); p.slab = slab;
     p.bytes_q = (unsigned)((((size_t)B * T - 1) * ld_qkv + nh * hd) * esz);
     p.scale = 1.0f / sqrtf((float)hd);
-    p.thr = ds6g_drop_threshold(drop_p); p.dscale = 1.f / (1.f - drop_p); p.seed = seed; p.seed_off = seed_off; p.salt = g_ds6g_salt;
+    ds6g_attn_drop_params(drop_p, &p.thr, &p.dscale); p.seed = seed; p.seed_off = seed_off; p.salt = g_ds6g_salt;
     const int ntiles = cdiv(T, 32);
     const int qblocks = cdiv(T, 128);
     const int per_cu = 3;  // measured (tools/bench_attn.py, DBG bits 20-23): 3 is best or tied for every head dim
@@ -1349,7 +1349,7 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, in
     p.bytes = (unsigned)(slab * esz); p.slab = slab;
     p.bytes_q = (unsigned)((((size_t)B * T - 1) * ld_qkv + nh * hd) * esz);
     p.scale = 1.0f / sqrtf((float)hd);
-    p.thr = ds6g_drop_threshold(drop_p); p.dscale = 1.f / (1.f - drop_p); p.seed = seed; p.seed_off = seed_off; p.salt = g_ds6g_salt;
+    ds6g_attn_drop_params(drop_p, &p.thr, &p.dscale); p.seed = seed; p.seed_off = seed_off; p.salt = g_ds6g_salt;
     const int ntiles = cdiv(T, 32);
     const int blocks128 = cdiv(T, 128);
     const int cols4 = nh * hd / 4;

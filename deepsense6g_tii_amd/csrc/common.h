@@ -270,6 +270,17 @@ static inline uint32_t ds6g_drop_threshold(float p) {
     return (uint32_t)t;
 }
 
+// attn_drop sites draw four 16-bit decisions per hash (ds6g_keep4): the drop probability they realise is floor(p * 2^16) / 2^16,
+// not p.  The inverted-dropout scale follows the REALISED probability so that E[mask * scale] = 1 (at p = 0.1 the exact-p scale
+// is off by 1e-5); a probability below 2^-16 drops nothing and is treated as no dropout (scale 1, threshold 0).
+static inline void ds6g_attn_drop_params(float p, uint32_t* thr, float* dscale) {
+    uint32_t t = ds6g_drop_threshold(p);
+    const uint32_t t16 = t >> 16;
+    if (t16 == 0) { *thr = 0u; *dscale = 1.f; return; }
+    *thr = t;
+    *dscale = 1.f / (1.f - (float)t16 * (1.f / 65536.f));
+}
+
 __device__ __forceinline__ float wave_reduce_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

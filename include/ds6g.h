@@ -64,7 +64,8 @@ int ds6g_get_compute_mode(void);
  * (attn_drop on the [B * nh][T][T] probabilities) draw FOUR decisions per hash: element (row, key), row = (b * nh + h) * T +
  * query, uses counter = seed_off + row * ceil(T / 4) + (key >> 2) and the 16-bit half (key & 3) of the two words derived
  * from that counter, dropped when the half < floor(p * 2^16) (csrc/common.h Ds6gKeep4Base; numpy restatement in
- * tests/test_bench_shapes_gpu.py::_keep_bits_attn).  seed_off is a launch argument, frozen when a
+ * tests/test_bench_shapes_gpu.py::_keep_bits_attn); kept probabilities are scaled by 1 / (1 - floor(p * 2^16) / 2^16), the
+ * probability the 16-bit decisions realise (p < 2^-16: no dropout); the elementwise sites scale by 1 / (1 - p).  seed_off is a launch argument, frozen when a
  * training step is captured into a hipGraph; ds6g_set_dropout_salt(dev_ptr) makes every kernel that draws a mask add the
  * uint64 at dev_ptr to seed_off when it RUNS (the caller advances that value on the device once per step), so replays draw
  * fresh masks.  Applies to the launches of the calling thread from now on (thread-local); NULL switches it off. */

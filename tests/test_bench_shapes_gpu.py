@@ -150,14 +150,20 @@ def _keep_bits_site(seed, off, shape, p):
     return _keep_bits(seed, off, int(np.prod(shape)), p).reshape(shape)
 
 
-def _drop_scale(p):
-    return float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))   # the kernels' fp32 1/(1-p)
+def _drop_scale(p, shape=None):
+    """the kernels' fp32 inverted-dropout scale: 1 / (1 - p) at the one-decision-per-hash sites; at the attention-probability
+    sites (4-D shapes: four 16-bit decisions per hash) 1 / (1 - floor(p 2^16) / 2^16), the probability the mask realises
+    (csrc/common.h ds6g_attn_drop_params)"""
+    if shape is not None and len(shape) == 4:
+        t16 = int(float(np.float32(p)) * 4294967296.0) >> 16
+        return float(np.float32(1.0) / (np.float32(1.0) - np.float32(t16) * np.float32(1.0 / 65536.0))) if t16 else 1.0
+    return float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
 
 
 def _keep_mask(seed, off, shape, p, dtype=torch.float32):
-    """-> keep mask scaled by the kernels' fp32 1/(1-p)"""
+    """-> keep mask scaled by the kernels' fp32 scale"""
     bits = torch.from_numpy(_keep_bits_site(seed, off, tuple(shape), p))
-    return bits.to(dtype) * _drop_scale(p)
+    return bits.to(dtype) * _drop_scale(p, shape)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -392,7 +398,7 @@ class _MaskBook:
         if bits is None:
             bits = self.cache[off] = torch.from_numpy(_keep_bits_site(self.seed, off, tuple(shape), p))
         assert bits.shape == tuple(shape)
-        return bits, _drop_scale(p)
+        return bits, _drop_scale(p, shape)
 
 
 class _MaskFn:
