@@ -287,6 +287,14 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
             const unsigned sa = (unsigned)(u_kpos * p.K) * 2u;
             const int ihu = u_oh * p.stride, iwu = u_ow * p.stride;
             const unsigned sb = (unsigned)(((u_n * p.H + ihu) * p.W + iwu) * p.C) * 2u;
+            if (rows_left >= BK && p.R == 1 && p.pad == 0) {
+                // whole k-tile of a filter without halo (the linears, the 1x1 convs): every test below is the lane constant
+                // of the set-up - no per-piece VALU between the DMA instructions
+#pragma unroll
+                for (int i = 0; i < A_LD; ++i) dma16(a_rsrc, la + (unsigned)(i * 4 + wave) * 1024u, a_ok[i] ? a_vo[i] : OOB_OFF, sa);
+#pragma unroll
+                for (int i = 0; i < B_LD; ++i) dma16(b_rsrc, lb + (unsigned)(i * 4 + wave) * 1024u, b_ok[i] ? b_vo[i] : OOB_OFF, sb);
+            } else {
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) {
                 const bool ok = a_ok[i] && a_kr[i] < rows_left;
@@ -297,6 +305,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams pin) {
                 const bool ok = b_ok[i] && b_kr[i] < rows_left && (unsigned)(ihu + b_ihl[i]) < (unsigned)p.H &&
                                 (unsigned)(iwu + b_iwl[i]) < (unsigned)p.W;
                 dma16(b_rsrc, lb + (unsigned)(i * 4 + wave) * 1024u, ok ? b_vo[i] : OOB_OFF, sb);
+            }
             }
             u_kpos += BK;
             if (p.wg_rows == 0) {
