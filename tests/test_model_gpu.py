@@ -174,8 +174,18 @@ def test_gradients_match_oracle_and_golden(run_b2):
             g = r["grads"][name]
             head = g.flatten()[:16]  # .flatten() of the channels_last view walks the logical OIHW order
             scale = float(gold[f"grad:{name}:absmax"])
-            assert (head - torch.from_numpy(gold[key])).abs().max().item() < 0.1 * scale, name
-            assert abs(float(g.norm()) - float(gold[f"grad:{name}:l2"])) < 0.05 * float(gold[f"grad:{name}:l2"]), name
+            e_head = (head - torch.from_numpy(gold[key])).abs().max().item() / scale
+            e_norm = abs(float(g.norm()) - float(gold[f"grad:{name}:l2"])) / float(gold[f"grad:{name}:l2"])
+            print(f"reference fixture {name}: head {e_head:.2e} of the largest entry, norm {e_norm:.2e}", flush=True)
+            # per-tensor bars (round 4; 10 % / 5 % for every tensor before), ~10x what is measured on MI355X (head / norm):
+            # join.4.bias 3.5e-7 / 8e-8, transformer4.blocks.7.mlp.2 8e-8 / 1e-7, vel_emb1 3e-6 / 3e-7, radar layer4 bn2 2e-5 /
+            # 4e-7, transformer1.pos_emb 1e-3 / 3e-5, camera stem conv1 3e-3 / 3e-5 - the deeper the tensor sits below ReLU /
+            # max-pool decisions, the larger single entries move; the norms stay at 1e-5-class everywhere
+            bars = {"join.4.bias": (1e-5, 1e-5), "encoder.transformer4.blocks.7.mlp.2.weight": (1e-5, 1e-5),
+                    "encoder.vel_emb1.weight": (1e-4, 1e-5), "encoder.radar_encoder._model.layer4.1.bn2.weight": (1e-3, 1e-4),
+                    "encoder.transformer1.pos_emb": (1e-2, 1e-3), "encoder.image_encoder.features.conv1.weight": (3e-2, 1e-3)}
+            bar_head, bar_norm = bars[name]
+            assert e_head < bar_head and e_norm < bar_norm, (name, e_head, e_norm)
 
 
 def test_autograd_boundary_and_grad_accumulation(dev):
