@@ -1160,7 +1160,10 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 }
 
 // number of loop splits: fills the chip evenly.  cap = workgroups resident at once (256 CUs x per-CU residency)
-int pick_splits(long base_blocks, int ntiles, int per_cu, int max_splits) {
+// pen: what one more split costs in loop trips (its share of the merge / slab-sum kernel and of the prologue).  0.35 for the
+// fp32-storage kernels; 4 on the bf16-stored path, where a tile step is 3 - 4x shorter while the merge kernels cost the same
+// (measured: bf16 step 451.9 -> 460.3 samples/s at 4, 459.5 at 8; fp32 184.5 at 0.35, 183.4 at 4).  DS6G_ATTN_SPLIT_PENALTY overrides.
+int pick_splits(long base_blocks, int ntiles, int per_cu, int max_splits, double pen_default = 0.35) {
     if (g_ds6g_attn_percu > 0) per_cu = g_ds6g_attn_percu;  // timing experiments (ds6g_set_debug_flags bits 20-23)
     const long cap = 256L * per_cu;
     int best = 1;
@@ -1169,7 +1172,9 @@ int pick_splits(long base_blocks, int ntiles, int per_cu, int max_splits) {
         const int tps = cdiv(ntiles, s);
         const int eff = cdiv(ntiles, tps);  // splits actually used
         const long rounds = cdiv(base_blocks * eff, cap);
-        const double cost = (double)rounds * tps + 0.35 * eff;  // loop trips per CU slot + a merge/prologue penalty
+        static const double pen_env = [] { const char* e = getenv("DS6G_ATTN_SPLIT_PENALTY"); return e ? atof(e) : -1.0; }();
+        const double pen = pen_env >= 0.0 ? pen_env : pen_default;
+        const double cost = (double)rounds * tps + pen * eff;  // loop trips per CU slot + a merge/prologue penalty
         if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
     }
     return best;
@@ -1289,7 +1294,7 @@ static int attention_fwd_impl(const float* q, const float* k, const float* v, in
     const int qblocks = cdiv(T, 128);
     const int per_cu = 3;  // measured (tools/bench_attn.py, DBG bits 20-23): 3 is best or tied for every head dim
     const size_t max_by_ws = ws ? ws_bytes / (slab * sizeof(float) + (size_t)B * nh * T * 2 * sizeof(float)) : 1;
-    int splits = pick_splits((long)qblocks * nh * B, ntiles, per_cu, (int)(max_by_ws < 8 ? max_by_ws : 8));
+    int splits = pick_splits((long)qblocks * nh * B, ntiles, per_cu, (int)(max_by_ws < 8 ? max_by_ws : 8), in16 ? 4.0 : 0.35);
     if (splits < 1) splits = 1;
     p.tiles_per_split = cdiv(ntiles, splits);
     splits = cdiv(ntiles, p.tiles_per_split);
@@ -1367,7 +1372,7 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, in
         DS6G_LAUNCH_CHECK();
         auto plan = [&](int per_cu, size_t slabs_per_split) {
             const size_t cap = wsb / (slabs_per_split * slab * sizeof(float));
-            int splits = pick_splits((long)blocks128 * nh * B, ntiles, per_cu, (int)(cap < 8 ? cap : 8));
+            int splits = pick_splits((long)blocks128 * nh * B, ntiles, per_cu, (int)(cap < 8 ? cap : 8), in16 ? 4.0 : 0.35);
             if (splits < 1) splits = 1;
             p.tiles_per_split = cdiv(ntiles, splits);
             p.splits = cdiv(ntiles, p.tiles_per_split);
